@@ -1,0 +1,15 @@
+"""CPU oracle for the sparse Lucas-Kanade hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package,
+and only as the checker or the timed CPU baseline.  The product
+(iceberg_tracking_code_amd) never imports it.
+
+PARITY UNPINNED: the reference's arithmetic for this path lives in OpenCV, which is neither in
+/root/reference nor installed here, and the reference ships no fixtures for it.  See the header
+of icelk_oracle.c.
+"""
+from .cpu import (  # noqa: F401
+    CRIT_COUNT, CRIT_EPS, FLAG_INITIAL_FLOW, FLAG_MIN_EIGENVALS,
+    build, lib, set_threads, bgr2gray, pyrdown, pyramid_levels, build_pyramid, scharr,
+    pyrlk, track_fb, min_eig_map, good_features,
+)

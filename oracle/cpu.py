@@ -1,0 +1,200 @@
+"""ctypes front end of oracle/libicelk_oracle.so (built from icelk_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  Argument shapes follow the cv2 calls the
+reference makes (s1_lucaskanade_tracking.py:311,323,326,437).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libicelk_oracle.so")
+
+CRIT_COUNT = 1
+CRIT_EPS = 2
+FLAG_INITIAL_FLOW = 4
+FLAG_MIN_EIGENVALS = 8
+
+_lib = None
+_u8p = C.POINTER(C.c_uint8)
+_f32p = C.POINTER(C.c_float)
+_i16p = C.POINTER(C.c_int16)
+_i32p = C.POINTER(C.c_int)
+
+
+def build(force=False):
+    """Compile the C restatement with the committed Makefile (gcc only)."""
+    src = os.path.join(_HERE, "icelk_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_bgr2gray.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]
+        L.orc_pyrdown.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]
+        L.orc_pyramid_levels.argtypes = [C.c_int] * 5
+        L.orc_build_pyramid.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _i32p]
+        L.orc_scharr.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _i16p, C.c_int]
+        L.orc_pyrlk.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _u8p, _f32p,
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                C.c_double]
+        L.orc_track_fb.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _u8p,
+                                   _u8p, _f32p, _f32p, _f32p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_double, C.c_double, C.c_float]
+        L.orc_min_eig_map.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+        L.orc_good_features.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_double,
+                                        C.c_double, C.c_int, _f32p, C.c_int, _i32p]
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _gray(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 2:
+        raise ValueError("expected HxW uint8 image")
+    return a
+
+
+def _chk(rc):
+    if rc < 0:
+        raise RuntimeError("oracle error %d" % rc)
+    return rc
+
+
+def set_threads(n):
+    return lib().orc_set_threads(int(n))
+
+
+def bgr2gray(src, variant=3):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w, c = src.shape
+    assert c == 3
+    dst = np.empty((h, w), np.uint8)
+    _chk(lib().orc_bgr2gray(_p(src, _u8p), w, h, 3 * w, _p(dst, _u8p), w, variant))
+    return dst
+
+
+def pyrdown(img):
+    img = _gray(img)
+    h, w = img.shape
+    dst = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    _chk(lib().orc_pyrdown(_p(img, _u8p), w, h, w, _p(dst, _u8p), dst.shape[1]))
+    return dst
+
+
+def pyramid_levels(w, h, win, max_level):
+    return lib().orc_pyramid_levels(w, h, win[0], win[1], max_level)
+
+
+def build_pyramid(img, win=(21, 21), max_level=3):
+    """Returns the list of level images that buildOpticalFlowPyramid would hold (unpadded)."""
+    img = _gray(img)
+    h, w = img.shape
+    out = np.empty(2 * w * h, np.uint8)
+    nlev = C.c_int(0)
+    _chk(lib().orc_build_pyramid(_p(img, _u8p), w, h, w, win[0], win[1], max_level, _p(out, _u8p), C.byref(nlev)))
+    levels, off = [], 0
+    lw, lh = w, h
+    for _ in range(nlev.value + 1):
+        levels.append(out[off:off + lw * lh].reshape(lh, lw).copy())
+        off += lw * lh
+        lw, lh = (lw + 1) // 2, (lh + 1) // 2
+    return levels
+
+
+def scharr(img):
+    img = _gray(img)
+    h, w = img.shape
+    dst = np.empty((h, w, 2), np.int16)
+    _chk(lib().orc_scharr(_p(img, _u8p), w, h, w, _p(dst, _i16p), 2 * w))
+    return dst
+
+
+def _crit(criteria):
+    t, cnt, eps = criteria
+    return int(t), int(cnt), float(eps)
+
+
+def pyrlk(prev, nxt, prev_pts, next_pts=None, winSize=(21, 21), maxLevel=3,
+          criteria=(CRIT_COUNT | CRIT_EPS, 30, 0.01), flags=0, minEigThreshold=1e-4):
+    """cv2.calcOpticalFlowPyrLK-shaped: returns (nextPts (N,1,2) f32, status (N,1) u8, err (N,1) f32)."""
+    prev, nxt = _gray(prev), _gray(nxt)
+    assert prev.shape == nxt.shape
+    h, w = prev.shape
+    p0 = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(-1, 2)
+    n = p0.shape[0]
+    if flags & FLAG_INITIAL_FLOW:
+        p1 = np.ascontiguousarray(next_pts, dtype=np.float32).reshape(-1, 2).copy()
+    else:
+        p1 = np.zeros((n, 2), np.float32)
+    st = np.zeros(n, np.uint8)
+    er = np.zeros(n, np.float32)
+    t, cnt, eps = _crit(criteria)
+    _chk(lib().orc_pyrlk(_p(prev, _u8p), w, _p(nxt, _u8p), w, w, h, _p(p0, _f32p), _p(p1, _f32p), _p(st, _u8p),
+                         _p(er, _f32p), n, winSize[0], winSize[1], maxLevel, t, cnt, eps, flags, minEigThreshold))
+    return p1.reshape(-1, 1, 2), st.reshape(-1, 1), er.reshape(-1, 1)
+
+
+def track_fb(img0, img1, p0, winSize=(21, 21), maxLevel=3, criteria=(CRIT_COUNT | CRIT_EPS, 30, 0.01),
+             minEigThreshold=1e-4, fb_threshold=1.0):
+    """The reference's forward + backward + distance test (s1:323-333) in one call."""
+    img0, img1 = _gray(img0), _gray(img1)
+    h, w = img0.shape
+    p0 = np.ascontiguousarray(p0, dtype=np.float32).reshape(-1, 2)
+    n = p0.shape[0]
+    p1 = np.zeros((n, 2), np.float32)
+    p0r = np.zeros((n, 2), np.float32)
+    st_f = np.zeros(n, np.uint8)
+    st_b = np.zeros(n, np.uint8)
+    er_f = np.zeros(n, np.float32)
+    er_b = np.zeros(n, np.float32)
+    dist = np.zeros(n, np.float32)
+    valid = np.zeros(n, np.uint8)
+    t, cnt, eps = _crit(criteria)
+    _chk(lib().orc_track_fb(_p(img0, _u8p), w, _p(img1, _u8p), w, w, h, _p(p0, _f32p), _p(p1, _f32p),
+                            _p(p0r, _f32p), _p(st_f, _u8p), _p(st_b, _u8p), _p(er_f, _f32p), _p(er_b, _f32p),
+                            _p(dist, _f32p), _p(valid, _u8p), n, winSize[0], winSize[1], maxLevel, t, cnt, eps,
+                            minEigThreshold, fb_threshold))
+    return dict(p1=p1, p0r=p0r, st_fwd=st_f, st_bwd=st_b, err_fwd=er_f, err_bwd=er_b, dist=dist, valid=valid)
+
+
+def min_eig_map(img, blockSize=3):
+    img = _gray(img)
+    h, w = img.shape
+    eig = np.empty((h, w), np.float32)
+    _chk(lib().orc_min_eig_map(_p(img, _u8p), w, h, w, blockSize, _p(eig, _f32p)))
+    return eig
+
+
+def good_features(img, maxCorners, qualityLevel, minDistance, mask=None, blockSize=3):
+    """cv2.goodFeaturesToTrack-shaped: (M,1,2) float32, or None when nothing is found."""
+    img = _gray(img)
+    h, w = img.shape
+    cap = w * h if maxCorners <= 0 else int(maxCorners)
+    cap = min(cap, w * h)
+    out = np.empty((max(cap, 1), 2), np.float32)
+    n = C.c_int(0)
+    if mask is not None:
+        mask = _gray(mask)
+        assert mask.shape == img.shape
+        mp, ms = _p(mask, _u8p), w
+    else:
+        mp, ms = None, 0
+    _chk(lib().orc_good_features(_p(img, _u8p), w, h, w, mp, ms, int(maxCorners), float(qualityLevel),
+                                 float(minDistance), int(blockSize), _p(out, _f32p), cap, C.byref(n)))
+    if n.value == 0:
+        return None
+    return out[:n.value].reshape(-1, 1, 2).copy()
