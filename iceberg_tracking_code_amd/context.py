@@ -1,0 +1,230 @@
+"""Context: one GPU handle (icelk_t) with numpy-facing methods.
+
+This is the host side of the hot path: everything here is argument marshalling around the C ABI of
+include/icelk.h.  One Context per process per GPU (see DESIGN.md "Multi-GPU").
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f32p, u8p
+
+TERM_CRITERIA_COUNT = 1
+TERM_CRITERIA_MAX_ITER = 1
+TERM_CRITERIA_EPS = 2
+OPTFLOW_USE_INITIAL_FLOW = 4
+OPTFLOW_LK_GET_MIN_EIGENVALS = 8
+GRAY_CV3 = 3
+GRAY_CV4 = 4
+
+DEFAULT_CRITERIA = (TERM_CRITERIA_COUNT | TERM_CRITERIA_EPS, 30, 0.01)
+
+
+def _u8(a):
+    return a.ctypes.data_as(u8p)
+
+
+def _f32(a):
+    return a.ctypes.data_as(f32p)
+
+
+def _gray2d(img, name="image"):
+    a = np.asarray(img)
+    if a.dtype != np.uint8 or a.ndim != 2:
+        raise ValueError("%s must be a 2-D uint8 array (got %s %s)" % (name, a.dtype, a.shape))
+    if a.strides[1] != 1 or a.strides[0] < a.shape[1]:
+        a = np.ascontiguousarray(a)
+    return a
+
+
+def _criteria(criteria):
+    t, cnt, eps = criteria
+    return int(t), int(cnt), float(eps)
+
+
+class Context:
+    """Owns the device memory of `n_slots` resident frames (+ pyramids) and all point buffers."""
+
+    def __init__(self, max_w, max_h, n_slots=3, max_pts=1 << 18, device=0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.max_w, self.max_h, self.n_slots, self.max_pts, self.device = max_w, max_h, n_slots, max_pts, device
+        check(self._lib.icelk_create(device, max_w, max_h, n_slots, max_pts, C.byref(self._h)), None)
+
+    # -- lifetime -----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.icelk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc):
+        check(rc, self._h)
+
+    def set_stream(self, stream_ptr):
+        """Run on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream)."""
+        self._ck(self._lib.icelk_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def sync(self):
+        self._ck(self._lib.icelk_sync(self._h))
+
+    # -- ingest -------------------------------------------------------------------------------
+    def upload_gray(self, slot, img):
+        a = _gray2d(img)
+        self._ck(self._lib.icelk_upload_gray(self._h, slot, _u8(a), a.shape[1], a.shape[0], a.strides[0]))
+
+    def upload_bgr(self, slot, img, variant=GRAY_CV3):
+        a = np.asarray(img)
+        if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("expected HxWx3 uint8 image")
+        a = np.ascontiguousarray(a)
+        self._ck(self._lib.icelk_upload_bgr(self._h, slot, _u8(a), a.shape[1], a.shape[0], a.strides[0], variant))
+
+    def set_gray_device(self, slot, dev_ptr, w, h, stride):
+        self._ck(self._lib.icelk_set_gray_device(self._h, slot, C.c_void_p(dev_ptr), w, h, stride))
+
+    def cvt_bgr_device(self, slot, dev_ptr, w, h, stride, variant=GRAY_CV3):
+        self._ck(self._lib.icelk_cvt_bgr_device(self._h, slot, C.c_void_p(dev_ptr), w, h, stride, variant))
+
+    def upload_gray_async(self, slot, pinned_ptr, w, h, stride):
+        self._ck(self._lib.icelk_upload_gray_async(self._h, slot, C.c_void_p(pinned_ptr), w, h, stride))
+
+    def synth_frame(self, slot, w, h, ux=0, uy=0, seed=1234):
+        self._ck(self._lib.icelk_synth_frame(self._h, slot, w, h, int(ux), int(uy), int(seed)))
+
+    def download_level(self, slot, level=0):
+        w, h = C.c_int(0), C.c_int(0)
+        self._ck(self._lib.icelk_download_level(self._h, slot, level, None, 0, C.byref(w), C.byref(h)))
+        out = np.empty((h.value, w.value), np.uint8)
+        self._ck(self._lib.icelk_download_level(self._h, slot, level, _u8(out), w.value, C.byref(w), C.byref(h)))
+        return out
+
+    def build_pyramid(self, slot, winSize=(21, 21), maxLevel=3):
+        n = C.c_int(0)
+        self._ck(self._lib.icelk_build_pyramid(self._h, slot, winSize[0], winSize[1], maxLevel, C.byref(n)))
+        return n.value
+
+    # -- tracker ------------------------------------------------------------------------------
+    def pyrlk(self, prev_slot, next_slot, prev_pts, next_pts=None, winSize=(21, 21), maxLevel=3,
+              criteria=DEFAULT_CRITERIA, flags=0, minEigThreshold=1e-4):
+        p0 = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(-1, 2)
+        n = p0.shape[0]
+        if flags & OPTFLOW_USE_INITIAL_FLOW:
+            if next_pts is None:
+                raise ValueError("OPTFLOW_USE_INITIAL_FLOW needs nextPts")
+            p1 = np.ascontiguousarray(next_pts, dtype=np.float32).reshape(-1, 2).copy()
+            if p1.shape[0] != n:
+                raise ValueError("nextPts and prevPts differ in length")
+        else:
+            p1 = np.zeros((n, 2), np.float32)
+        st = np.zeros(n, np.uint8)
+        er = np.zeros(n, np.float32)
+        t, cnt, eps = _criteria(criteria)
+        self._ck(self._lib.icelk_pyrlk(self._h, prev_slot, next_slot, _f32(p0), _f32(p1), _u8(st), _f32(er), n,
+                                       winSize[0], winSize[1], maxLevel, t, cnt, eps, flags, minEigThreshold))
+        return p1.reshape(-1, 1, 2), st.reshape(-1, 1), er.reshape(-1, 1)
+
+    def track_fb(self, slot0, slot1, p0, winSize=(21, 21), maxLevel=3, criteria=DEFAULT_CRITERIA,
+                 minEigThreshold=1e-4, fb_threshold=1.0):
+        p0 = np.ascontiguousarray(p0, dtype=np.float32).reshape(-1, 2)
+        n = p0.shape[0]
+        out = dict(p1=np.zeros((n, 2), np.float32), p0r=np.zeros((n, 2), np.float32),
+                   st_fwd=np.zeros(n, np.uint8), st_bwd=np.zeros(n, np.uint8),
+                   err_fwd=np.zeros(n, np.float32), err_bwd=np.zeros(n, np.float32),
+                   dist=np.zeros(n, np.float32), valid=np.zeros(n, np.uint8))
+        t, cnt, eps = _criteria(criteria)
+        self._ck(self._lib.icelk_track_fb(self._h, slot0, slot1, _f32(p0), n, winSize[0], winSize[1], maxLevel, t,
+                                          cnt, eps, minEigThreshold, fb_threshold, _f32(out["p1"]),
+                                          _f32(out["p0r"]), _u8(out["st_fwd"]), _u8(out["st_bwd"]),
+                                          _f32(out["err_fwd"]), _f32(out["err_bwd"]), _f32(out["dist"]),
+                                          _u8(out["valid"])))
+        return out
+
+    # -- detector -----------------------------------------------------------------------------
+    def set_mask(self, mask):
+        if mask is None:
+            self._ck(self._lib.icelk_set_mask(self._h, None, 0, 0, 0))
+            return
+        m = _gray2d(mask, "mask")
+        self._ck(self._lib.icelk_set_mask(self._h, _u8(m), m.shape[1], m.shape[0], m.strides[0]))
+
+    def min_eig_map(self, slot, blockSize=3):
+        lvl = self.download_level(slot, 0)
+        out = np.empty(lvl.shape, np.float32)
+        self._ck(self._lib.icelk_min_eig_map(self._h, slot, blockSize, _f32(out), out.shape[1]))
+        return out
+
+    def good_features(self, slot, maxCorners, qualityLevel, minDistance, use_mask=False, blockSize=3):
+        cap = self.max_pts if maxCorners <= 0 else min(int(maxCorners), self.max_pts)
+        out = np.empty((max(cap, 1), 2), np.float32)
+        n = C.c_int(0)
+        self._ck(self._lib.icelk_good_features(self._h, slot, 1 if use_mask else 0, int(maxCorners),
+                                               float(qualityLevel), float(minDistance), int(blockSize), _f32(out), cap,
+                                               C.byref(n)))
+        if n.value == 0:
+            return None
+        return out[:n.value].reshape(-1, 1, 2).copy()
+
+    # -- device-resident segment state ----------------------------------------------------------
+    def seg_detect(self, slot, maxCorners, qualityLevel, minDistance, use_mask=False, blockSize=3):
+        n = C.c_int(0)
+        self._ck(self._lib.icelk_seg_detect(self._h, slot, 1 if use_mask else 0, int(maxCorners), float(qualityLevel),
+                                            float(minDistance), int(blockSize), C.byref(n)))
+        return n.value
+
+    def seg_track(self, slot_prev, slot_next, winSize=(21, 21), maxLevel=3, criteria=DEFAULT_CRITERIA,
+                  minEigThreshold=1e-4, fb_threshold=1.0, wait=True):
+        t, cnt, eps = _criteria(criteria)
+        if wait:
+            n = C.c_int(0)
+            self._ck(self._lib.icelk_seg_track(self._h, slot_prev, slot_next, winSize[0], winSize[1], maxLevel, t, cnt,
+                                               eps, minEigThreshold, fb_threshold, C.byref(n)))
+            return n.value
+        self._ck(self._lib.icelk_seg_track_async(self._h, slot_prev, slot_next, winSize[0], winSize[1], maxLevel, t,
+                                                 cnt, eps, minEigThreshold, fb_threshold))
+        return None
+
+    def seg_live(self):
+        n, tot = C.c_int(0), C.c_int64(0)
+        self._ck(self._lib.icelk_seg_live(self._h, C.byref(n), C.byref(tot)))
+        return n.value, tot.value
+
+    def seg_read(self):
+        """(tracks (n, V, 2) f32, trackquality (n, V-1) f32): what np.savez stores at s1:394-395."""
+        n, nv = C.c_int(0), C.c_int(0)
+        self._ck(self._lib.icelk_seg_read(self._h, None, None, 0, 0, C.byref(n), C.byref(nv)))
+        tracks = np.zeros((n.value, nv.value, 2), np.float32)
+        quality = np.zeros((n.value, max(nv.value - 1, 0)), np.float32)
+        if n.value:
+            self._ck(self._lib.icelk_seg_read(self._h, _f32(tracks), _f32(quality), n.value, nv.value, C.byref(n),
+                                              C.byref(nv)))
+        return tracks, quality
+
+    # -- measurement ----------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._ck(self._lib.icelk_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._ck(self._lib.icelk_prof_reset(self._h))
+
+    def prof_table(self):
+        out = {}
+        for k in range(self._lib.icelk_prof_count()):
+            n, ms = C.c_int(0), C.c_double(0)
+            self._ck(self._lib.icelk_prof_get(self._h, k, C.byref(n), C.byref(ms)))
+            if n.value:
+                out[self._lib.icelk_prof_name(k).decode()] = dict(launches=n.value, total_ms=ms.value,
+                                                                  avg_us=1e3 * ms.value / n.value)
+        return out

@@ -1,0 +1,997 @@
+// icelk_abi.hip -- handle, device memory and the extern "C" entry points declared in include/icelk.h.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+
+#include "icelk_internal.h"
+
+namespace icelk {
+
+constexpr int kMaxVert = 17;  // vertices per track kept on the device (track_len <= 16; reference uses 2)
+
+static const char* kKernelNames[K_COUNT_] = {
+    "bgr2gray", "pyrdown", "lk", "lk_fb", "min_eig", "nms_collect", "cells", "suppress", "emit", "compact", "synth",
+};
+
+struct Ctx {
+    int device = 0;
+    int max_w = 0, max_h = 0, n_slots = 0, max_pts = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
+    std::vector<Slot> slots;
+    std::string err;
+
+    // staging for 3-channel uploads
+    uint8_t* d_bgr = nullptr;
+    int bgr_pitch = 0;
+    // detector mask
+    uint8_t* d_mask = nullptr;
+    int mask_pitch = 0;
+    bool has_mask = false;
+    int mask_w = 0, mask_h = 0;
+
+    // point buffers
+    float *d_p0 = nullptr, *d_p1 = nullptr, *d_p0r = nullptr, *d_err_f = nullptr, *d_err_b = nullptr,
+          *d_dist = nullptr, *d_corners = nullptr;
+    uint8_t *d_st_f = nullptr, *d_st_b = nullptr, *d_valid = nullptr;
+
+    DetectScratch D{};
+    size_t ncell_cap = 0;
+
+    // segment state
+    float* d_live[2] = {nullptr, nullptr};
+    int* d_origin[2] = {nullptr, nullptr};
+    int* d_nlive = nullptr;   // [2]
+    unsigned long long* d_tracked = nullptr;
+    float *d_tracks = nullptr, *d_quality = nullptr, *d_out_tracks = nullptr, *d_out_quality = nullptr;
+    int seg_cur = 0, seg_vert = 0, seg_upper = 0;
+    bool seg_active = false;
+
+    // profiling
+    bool prof = false;
+    std::vector<ProfEvt> evts;
+    int prof_launches[K_COUNT_] = {0};
+    double prof_ms[K_COUNT_] = {0};
+};
+
+static std::string g_create_err;
+static std::mutex g_mu;
+
+#define HIPCHK(c, expr)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (c)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            return ICELK_EHIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define FAIL(c, code, msg)   \
+    do {                     \
+        (c)->err = (msg);    \
+        return (code);       \
+    } while (0)
+
+static inline Ctx* C(icelk_t* h) { return reinterpret_cast<Ctx*>(h); }
+
+static int check_launch(Ctx* c, const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        c->err = std::string(what) + ": " + hipGetErrorString(e);
+        return ICELK_EHIP;
+    }
+    return ICELK_OK;
+}
+
+struct ProfScope {
+    Ctx* c;
+    int id;
+    ProfEvt ev{};
+    ProfScope(Ctx* c_, int id_) : c(c_), id(id_)
+    {
+        if (c->prof) {
+            hipEventCreate(&ev.a);
+            hipEventCreate(&ev.b);
+            ev.id = id;
+            hipEventRecord(ev.a, c->stream);
+        }
+    }
+    ~ProfScope()
+    {
+        if (c->prof) {
+            hipEventRecord(ev.b, c->stream);
+            c->evts.push_back(ev);
+        }
+    }
+};
+
+static void prof_drain(Ctx* c)
+{
+    for (auto& e : c->evts) {
+        hipEventSynchronize(e.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->prof_ms[e.id] += ms;
+            c->prof_launches[e.id] += 1;
+        }
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
+    c->evts.clear();
+}
+
+static int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// level geometry of a w x h frame inside a slot allocation
+static void layout_levels(Slot& s, int w, int h)
+{
+    size_t off = 0;
+    int lw = w, lh = h;
+    for (int l = 0; l < kMaxLevels; l++) {
+        s.lv[l].w = lw;
+        s.lv[l].h = lh;
+        s.lv[l].pitch = align_up(lw, kPitchAlign);
+        s.lv[l].ptr = s.base + off;
+        off += (size_t)s.lv[l].pitch * lh;
+        off = (off + 255) & ~(size_t)255;
+        lw = (lw + 1) / 2;
+        lh = (lh + 1) / 2;
+    }
+}
+
+static size_t slot_bytes(int w, int h)
+{
+    size_t off = 0;
+    int lw = w, lh = h;
+    for (int l = 0; l < kMaxLevels; l++) {
+        off += (size_t)align_up(lw, kPitchAlign) * lh;
+        off = (off + 255) & ~(size_t)255;
+        lw = (lw + 1) / 2;
+        lh = (lh + 1) / 2;
+    }
+    return off + 256;
+}
+
+static int pyramid_top_level(int w, int h, int win_w, int win_h, int max_level)
+{
+    for (int level = 0; level <= max_level; level++) {
+        w = (w + 1) / 2;
+        h = (h + 1) / 2;
+        if (w <= win_w || h <= win_h) return level;
+    }
+    return max_level;
+}
+
+static int check_slot(Ctx* c, int slot, bool need_image)
+{
+    if (slot < 0 || slot >= c->n_slots) FAIL(c, ICELK_EARG, "slot index out of range");
+    if (need_image && c->slots[slot].levels_built < 1) FAIL(c, ICELK_ESTATE, "slot holds no frame");
+    return ICELK_OK;
+}
+
+static int wait_slot(Ctx* c, int slot)
+{
+    Slot& s = c->slots[slot];
+    if (s.pending) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, s.ready, 0));
+        s.pending = false;
+    }
+    return ICELK_OK;
+}
+
+static int begin_frame(Ctx* c, int slot, int w, int h)
+{
+    int rc = check_slot(c, slot, false);
+    if (rc) return rc;
+    if (w <= 0 || h <= 0) FAIL(c, ICELK_EARG, "empty image");
+    if (w > c->max_w || h > c->max_h) FAIL(c, ICELK_ECAP, "frame larger than max_w x max_h of icelk_create");
+    Slot& s = c->slots[slot];
+    s.w = w;
+    s.h = h;
+    layout_levels(s, w, h);
+    s.levels_built = 0;
+    return ICELK_OK;
+}
+
+static int ensure_pyramid(Ctx* c, int slot, int top_level)
+{
+    Slot& s = c->slots[slot];
+    int rc = wait_slot(c, slot);
+    if (rc) return rc;
+    if (top_level + 1 > kMaxLevels) FAIL(c, ICELK_EARG, "maxLevel too large");
+    while (s.levels_built < top_level + 1) {
+        const int l = s.levels_built;
+        {
+            ProfScope p(c, K_PYRDOWN);
+            launch_pyrdown(c->stream, s.lv[l - 1], s.lv[l]);
+        }
+        rc = check_launch(c, "pyrdown");
+        if (rc) return rc;
+        s.levels_built++;
+    }
+    return ICELK_OK;
+}
+
+static Pyramid pyramid_of(const Slot& s)
+{
+    Pyramid p;
+    for (int l = 0; l < kMaxLevels; l++) p.lv[l] = s.lv[l];
+    return p;
+}
+
+static int make_lk_params(Ctx* c, int w, int h, int win_w, int win_h, int max_level, int crit_type, int max_count,
+                          double epsilon, int flags, double min_eig_thr, float fb_thr, LKParams* P)
+{
+    if (win_w <= 2 || win_h <= 2) FAIL(c, ICELK_EARG, "winSize must be > 2");
+    if (max_level < 0) FAIL(c, ICELK_EARG, "maxLevel must be >= 0");
+    if (max_level > kMaxLevels - 1) max_level = kMaxLevels - 1;
+    if (win_w * win_h > 64 * 64) FAIL(c, ICELK_EARG, "winSize area above 4096 px is not supported");
+    P->win_w = win_w;
+    P->win_h = win_h;
+    P->top_level = pyramid_top_level(w, h, win_w, win_h, max_level);
+    if (!(crit_type & ICELK_CRIT_COUNT)) max_count = 30;
+    else max_count = std::min(std::max(max_count, 0), 100);
+    if (!(crit_type & ICELK_CRIT_EPS)) epsilon = 0.01;
+    else epsilon = std::min(std::max(epsilon, 0.), 10.);
+    P->max_count = max_count;
+    P->eps2 = epsilon * epsilon;
+    P->flags = flags;
+    P->min_eig_thr = (float)min_eig_thr;
+    P->fb_thr = fb_thr;
+    P->margin = 6;
+    return ICELK_OK;
+}
+
+template <typename T>
+static int dmalloc(Ctx* c, T** p, size_t count)
+{
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (count ? count : 1));
+    if (e != hipSuccess) {
+        c->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return ICELK_ENOMEM;
+    }
+    return ICELK_OK;
+}
+
+static void destroy_ctx(Ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    prof_drain(c);
+    for (auto& s : c->slots) {
+        if (s.base) hipFree(s.base);
+        if (s.ready) hipEventDestroy(s.ready);
+    }
+    void* ptrs[] = {c->d_bgr, c->d_mask, c->d_p0, c->d_p1, c->d_p0r, c->d_err_f, c->d_err_b, c->d_dist, c->d_corners,
+                    c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.max_key, c->D.cand, c->D.cand_count,
+                    c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.cell_cand, c->D.state, c->D.undecided,
+                    c->D.acc, c->D.acc_sorted, c->D.acc_count, c->D.sort_tmp, c->d_live[0], c->d_live[1],
+                    c->d_origin[0], c->d_origin[1], c->d_nlive, c->d_tracked, c->d_tracks, c->d_quality,
+                    c->d_out_tracks, c->d_out_quality};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    delete c;
+}
+
+// ---- detector core shared by icelk_good_features and icelk_seg_detect --------------------------
+// On success the first *n_out corners are in c->d_corners (device), in response order.
+static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double quality, double min_distance,
+                       int block_size, int cap, int* n_out)
+{
+    int rc = check_slot(c, slot, true);
+    if (rc) return rc;
+    if (!(quality > 0) || min_distance < 0 || block_size <= 0) FAIL(c, ICELK_EARG, "bad detector parameters");
+    if (min_eig_lds_bytes(block_size) > 150 * 1024) FAIL(c, ICELK_EARG, "blockSize too large");
+    rc = wait_slot(c, slot);
+    if (rc) return rc;
+    Slot& s = c->slots[slot];
+    const int w = s.w, h = s.h;
+    const uint8_t* mask = nullptr;
+    if (use_mask) {
+        if (!c->has_mask) FAIL(c, ICELK_ESTATE, "use_mask set but no mask uploaded");
+        if (c->mask_w != w || c->mask_h != h) FAIL(c, ICELK_EARG, "mask size differs from the frame");
+        mask = c->d_mask;
+    }
+    DetectScratch& D = c->D;
+    *n_out = 0;
+    HIPCHK(c, hipMemsetAsync(D.max_key, 0, sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemsetAsync(D.cand_count, 0, sizeof(int), c->stream));
+    {
+        ProfScope p(c, K_EIG);
+        launch_min_eig(c->stream, s.lv[0], block_size, D.eig, mask, c->mask_pitch, D.max_key);
+    }
+    rc = check_launch(c, "min_eig");
+    if (rc) return rc;
+    {
+        ProfScope p(c, K_NMS);
+        launch_nms_collect(c->stream, D.eig, w, h, mask, c->mask_pitch, D.max_key, quality, D.cand, D.cand_count,
+                           D.cand_cap);
+    }
+    rc = check_launch(c, "nms_collect");
+    if (rc) return rc;
+    int n_cand = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_cand, D.cand_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_cand == 0) return ICELK_OK;
+    if (n_cand > D.cand_cap) FAIL(c, ICELK_ECAP, "corner candidate buffer overflow");
+
+    const unsigned long long* sorted = nullptr;
+    int total = 0;
+    if (min_distance >= 1) {
+        const int cell = (int)lrint(min_distance);
+        const size_t ncell = (size_t)((w + cell - 1) / cell) * ((h + cell - 1) / cell);
+        if (ncell + 1 > c->ncell_cap) FAIL(c, ICELK_ECAP, "cell grid larger than allocated");
+        {
+            ProfScope p(c, K_SUPPRESS);
+            rc = run_min_distance(c->stream, D, w, h, n_cand, min_distance, c->err);
+        }
+        if (rc) return rc;
+        rc = check_launch(c, "min_distance");
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(&total, D.acc_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        sort_keys_desc(c->stream, D, D.acc, D.acc_sorted, total);
+        sorted = D.acc_sorted;
+    } else {
+        total = n_cand;
+        sort_keys_desc(c->stream, D, D.cand, D.cell_cand, total);
+        sorted = D.cell_cand;
+    }
+    rc = check_launch(c, "sort");
+    if (rc) return rc;
+    int n = total;
+    if (max_corners > 0 && n > max_corners) n = max_corners;
+    if (n > cap || n > c->max_pts) FAIL(c, ICELK_ECAP, "more corners than the output capacity (raise max_pts)");
+    {
+        ProfScope p(c, K_EMIT);
+        launch_emit_corners(c->stream, sorted, n, w, c->d_corners);
+    }
+    rc = check_launch(c, "emit");
+    if (rc) return rc;
+    *n_out = n;
+    return ICELK_OK;
+}
+
+// shared by icelk_seg_track / icelk_seg_track_async
+static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int win_h, int max_level, int crit_type,
+                          int max_count, double epsilon, double min_eig_threshold, float fb_threshold)
+{
+    int rc = check_slot(c, slot_prev, true);
+    if (!rc) rc = check_slot(c, slot_next, true);
+    if (rc) return rc;
+    if (!c->seg_active) FAIL(c, ICELK_ESTATE, "icelk_seg_detect has not been called");
+    if (c->seg_vert >= kMaxVert) FAIL(c, ICELK_ECAP, "segment longer than the device track table");
+    Slot& s0 = c->slots[slot_prev];
+    Slot& s1 = c->slots[slot_next];
+    if (s0.w != s1.w || s0.h != s1.h) FAIL(c, ICELK_EARG, "frame sizes differ");
+    LKParams P;
+    rc = make_lk_params(c, s0.w, s0.h, win_w, win_h, max_level, crit_type, max_count, epsilon, 0, min_eig_threshold,
+                        fb_threshold, &P);
+    if (rc) return rc;
+    rc = ensure_pyramid(c, slot_prev, P.top_level);
+    if (!rc) rc = ensure_pyramid(c, slot_next, P.top_level);
+    if (rc) return rc;
+    const int cur = c->seg_cur, nxt = cur ^ 1;
+    if (c->seg_upper > 0) {
+        LKBuffers B{};
+        B.p_in = c->d_live[cur];
+        B.p_fwd = c->d_p1;
+        B.st_fwd = c->d_st_f;
+        B.err_fwd = c->d_err_f;
+        B.p_bwd = c->d_p0r;
+        B.st_bwd = c->d_st_b;
+        B.err_bwd = c->d_err_b;
+        B.dist = c->d_dist;
+        B.valid = c->d_valid;
+        B.n_dev = c->d_nlive + cur;
+        {
+            ProfScope p(c, K_LK_FB);
+            rc = launch_lk(c->stream, pyramid_of(s0), pyramid_of(s1), B, c->seg_upper, P, true);
+        }
+        if (rc) FAIL(c, rc, "unsupported window size");
+        rc = check_launch(c, "lk_fb");
+        if (rc) return rc;
+    }
+    {
+        ProfScope p(c, K_COMPACT);
+        launch_compact(c->stream, c->d_p1, c->d_dist, c->d_valid, c->d_origin[cur], c->d_nlive + cur, c->d_live[nxt],
+                       c->d_origin[nxt], c->d_nlive + nxt, c->d_tracks, c->d_quality, c->seg_vert, kMaxVert,
+                       c->d_tracked);
+    }
+    rc = check_launch(c, "compact");
+    if (rc) return rc;
+    c->seg_cur = nxt;
+    c->seg_vert += 1;
+    return ICELK_OK;
+}
+
+}  // namespace icelk
+
+using namespace icelk;
+
+extern "C" {
+
+int icelk_version(void) { return 100; }
+
+const char* icelk_last_error(icelk_t* h)
+{
+    if (!h) return g_create_err.c_str();
+    return C(h)->err.c_str();
+}
+
+int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, icelk_t** out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!out || max_w <= 0 || max_h <= 0 || n_slots <= 0 || max_pts <= 0) {
+        g_create_err = "icelk_create: bad argument";
+        return ICELK_EARG;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_create_err = std::string("icelk_create: no HIP device (") + hipGetErrorString(e) + ")";
+        return ICELK_EHIP;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_err = "icelk_create: device index out of range";
+        return ICELK_EARG;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return ICELK_EHIP;
+    }
+    Ctx* c = new Ctx();
+    c->device = device;
+    c->max_w = max_w;
+    c->max_h = max_h;
+    c->n_slots = n_slots;
+    c->max_pts = max_pts;
+    int rc = ICELK_OK;
+    auto fail = [&](int code) {
+        g_create_err = c->err;
+        destroy_ctx(c);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        c->err = "hipStreamCreate failed";
+        return fail(ICELK_EHIP);
+    }
+    c->stream = c->own_stream;
+    c->slots.resize(n_slots);
+    const size_t sb = slot_bytes(max_w, max_h);
+    for (auto& s : c->slots) {
+        if ((rc = dmalloc(c, &s.base, sb))) return fail(rc);
+        s.bytes = sb;
+        if (hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess) {
+            c->err = "hipEventCreate failed";
+            return fail(ICELK_EHIP);
+        }
+    }
+    const size_t npx = (size_t)max_w * max_h;
+    c->bgr_pitch = align_up(3 * max_w, kPitchAlign);
+    c->mask_pitch = align_up(max_w, kPitchAlign);
+    const size_t np = (size_t)max_pts;
+    DetectScratch& D = c->D;
+    D.cand_cap = (int)std::min<size_t>(npx, (size_t)1 << 30);
+    c->ncell_cap = npx + 1;
+    D.sort_tmp_bytes = sort_tmp_bytes(D.cand_cap);
+    if ((rc = dmalloc(c, &c->d_bgr, (size_t)c->bgr_pitch * max_h)) || (rc = dmalloc(c, &c->d_mask, (size_t)c->mask_pitch * max_h)) ||
+        (rc = dmalloc(c, &c->d_p0, 2 * np)) || (rc = dmalloc(c, &c->d_p1, 2 * np)) || (rc = dmalloc(c, &c->d_p0r, 2 * np)) ||
+        (rc = dmalloc(c, &c->d_err_f, np)) || (rc = dmalloc(c, &c->d_err_b, np)) || (rc = dmalloc(c, &c->d_dist, np)) ||
+        (rc = dmalloc(c, &c->d_corners, 2 * np)) || (rc = dmalloc(c, &c->d_st_f, np)) || (rc = dmalloc(c, &c->d_st_b, np)) ||
+        (rc = dmalloc(c, &c->d_valid, np)) || (rc = dmalloc(c, &D.eig, npx)) || (rc = dmalloc(c, &D.max_key, 1)) ||
+        (rc = dmalloc(c, &D.cand, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.cand_count, 1)) ||
+        (rc = dmalloc(c, &D.cell_count, c->ncell_cap)) || (rc = dmalloc(c, &D.cell_start, c->ncell_cap)) ||
+        (rc = dmalloc(c, &D.cell_fill, c->ncell_cap)) || (rc = dmalloc(c, &D.cell_cand, (size_t)D.cand_cap)) ||
+        (rc = dmalloc(c, &D.state, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.undecided, 64)) ||
+        (rc = dmalloc(c, &D.acc, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.acc_sorted, (size_t)D.cand_cap)) ||
+        (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, (uint8_t**)&D.sort_tmp, D.sort_tmp_bytes)) ||
+        (rc = dmalloc(c, &c->d_live[0], 2 * np)) || (rc = dmalloc(c, &c->d_live[1], 2 * np)) ||
+        (rc = dmalloc(c, &c->d_origin[0], np)) || (rc = dmalloc(c, &c->d_origin[1], np)) || (rc = dmalloc(c, &c->d_nlive, 2)) ||
+        (rc = dmalloc(c, &c->d_tracked, 1)) || (rc = dmalloc(c, &c->d_tracks, np * kMaxVert * 2)) ||
+        (rc = dmalloc(c, &c->d_quality, np * (kMaxVert - 1))) || (rc = dmalloc(c, &c->d_out_tracks, np * kMaxVert * 2)) ||
+        (rc = dmalloc(c, &c->d_out_quality, np * (kMaxVert - 1))))
+        return fail(rc);
+    if (hipMemset(c->d_nlive, 0, 2 * sizeof(int)) != hipSuccess || hipMemset(c->d_tracked, 0, 8) != hipSuccess) {
+        c->err = "hipMemset failed";
+        return fail(ICELK_EHIP);
+    }
+    *out = reinterpret_cast<icelk_t*>(c);
+    return ICELK_OK;
+}
+
+int icelk_destroy(icelk_t* h)
+{
+    if (!h) return ICELK_EARG;
+    destroy_ctx(C(h));
+    return ICELK_OK;
+}
+
+int icelk_set_stream(icelk_t* h, void* hip_stream)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return ICELK_OK;
+}
+
+int icelk_sync(icelk_t* h)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICELK_OK;
+}
+
+// ---- ingest ------------------------------------------------------------------------------------
+int icelk_upload_gray(icelk_t* h, int slot, const uint8_t* host, int w, int h_, int stride)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    if (!host || stride < w) FAIL(c, ICELK_EARG, "bad host image");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = begin_frame(c, slot, w, h_);
+    if (rc) return rc;
+    Slot& s = c->slots[slot];
+    HIPCHK(c, hipMemcpy2DAsync(s.lv[0].ptr, s.lv[0].pitch, host, stride, w, h_, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    s.levels_built = 1;
+    s.pending = false;
+    return ICELK_OK;
+}
+
+int icelk_upload_gray_async(icelk_t* h, int slot, const uint8_t* pinned_host, int w, int h_, int stride)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    if (!pinned_host || stride < w) FAIL(c, ICELK_EARG, "bad host image");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = begin_frame(c, slot, w, h_);
+    if (rc) return rc;
+    Slot& s = c->slots[slot];
+    // the copy must not overtake kernels still reading this slot on the compute stream
+    HIPCHK(c, hipEventRecord(s.ready, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, s.ready, 0));
+    HIPCHK(c, hipMemcpy2DAsync(s.lv[0].ptr, s.lv[0].pitch, pinned_host, stride, w, h_, hipMemcpyHostToDevice,
+                               c->copy_stream));
+    HIPCHK(c, hipEventRecord(s.ready, c->copy_stream));
+    s.pending = true;
+    s.levels_built = 1;
+    return ICELK_OK;
+}
+
+int icelk_host_alloc(void** out, uint64_t bytes)
+{
+    if (!out) return ICELK_EARG;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? ICELK_OK : ICELK_ENOMEM;
+}
+
+int icelk_host_free(void* p) { return hipHostFree(p) == hipSuccess ? ICELK_OK : ICELK_EHIP; }
+
+int icelk_upload_bgr(icelk_t* h, int slot, const uint8_t* host, int w, int h_, int stride, int gray_variant)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    if (!host || stride < 3 * w) FAIL(c, ICELK_EARG, "bad host image");
+    if (gray_variant != ICELK_GRAY_CV3 && gray_variant != ICELK_GRAY_CV4) FAIL(c, ICELK_EARG, "bad gray variant");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = begin_frame(c, slot, w, h_);
+    if (rc) return rc;
+    Slot& s = c->slots[slot];
+    HIPCHK(c, hipMemcpy2DAsync(c->d_bgr, c->bgr_pitch, host, stride, 3 * (size_t)w, h_, hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope p(c, K_GRAY);
+        launch_bgr2gray(c->stream, c->d_bgr, c->bgr_pitch, s.lv[0].ptr, s.lv[0].pitch, w, h_, gray_variant);
+    }
+    rc = check_launch(c, "bgr2gray");
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    s.levels_built = 1;
+    s.pending = false;
+    return ICELK_OK;
+}
+
+int icelk_set_gray_device(icelk_t* h, int slot, const void* dev, int w, int h_, int stride)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    if (!dev || stride < w) FAIL(c, ICELK_EARG, "bad device image");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = begin_frame(c, slot, w, h_);
+    if (rc) return rc;
+    Slot& s = c->slots[slot];
+    HIPCHK(c, hipMemcpy2DAsync(s.lv[0].ptr, s.lv[0].pitch, dev, stride, w, h_, hipMemcpyDeviceToDevice, c->stream));
+    s.levels_built = 1;
+    s.pending = false;
+    return ICELK_OK;
+}
+
+int icelk_cvt_bgr_device(icelk_t* h, int slot, const void* dev_bgr, int w, int h_, int stride, int gray_variant)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    if (!dev_bgr || stride < 3 * w) FAIL(c, ICELK_EARG, "bad device image");
+    if (gray_variant != ICELK_GRAY_CV3 && gray_variant != ICELK_GRAY_CV4) FAIL(c, ICELK_EARG, "bad gray variant");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = begin_frame(c, slot, w, h_);
+    if (rc) return rc;
+    Slot& s = c->slots[slot];
+    {
+        ProfScope p(c, K_GRAY);
+        launch_bgr2gray(c->stream, reinterpret_cast<const uint8_t*>(dev_bgr), stride, s.lv[0].ptr, s.lv[0].pitch, w, h_,
+                        gray_variant);
+    }
+    rc = check_launch(c, "bgr2gray");
+    if (rc) return rc;
+    s.levels_built = 1;
+    s.pending = false;
+    return ICELK_OK;
+}
+
+int icelk_synth_frame(icelk_t* h, int slot, int w, int h_, int64_t ux, int64_t uy, uint32_t seed)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = begin_frame(c, slot, w, h_);
+    if (rc) return rc;
+    Slot& s = c->slots[slot];
+    {
+        ProfScope p(c, K_SYNTH);
+        launch_synth(c->stream, s.lv[0], ux, uy, seed);
+    }
+    rc = check_launch(c, "synth");
+    if (rc) return rc;
+    s.levels_built = 1;
+    s.pending = false;
+    return ICELK_OK;
+}
+
+int icelk_download_level(icelk_t* h, int slot, int level, uint8_t* host, int stride, int* w, int* h_)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = check_slot(c, slot, true);
+    if (rc) return rc;
+    Slot& s = c->slots[slot];
+    if (level < 0 || level >= s.levels_built) FAIL(c, ICELK_ESTATE, "pyramid level not built");
+    rc = wait_slot(c, slot);
+    if (rc) return rc;
+    const Level& L = s.lv[level];
+    if (w) *w = L.w;
+    if (h_) *h_ = L.h;
+    if (host) {
+        if (stride < L.w) FAIL(c, ICELK_EARG, "stride smaller than the level width");
+        HIPCHK(c, hipMemcpy2DAsync(host, stride, L.ptr, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return ICELK_OK;
+}
+
+int icelk_build_pyramid(icelk_t* h, int slot, int win_w, int win_h, int max_level, int* out_levels)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = check_slot(c, slot, true);
+    if (rc) return rc;
+    if (win_w <= 2 || win_h <= 2 || max_level < 0) FAIL(c, ICELK_EARG, "bad pyramid parameters");
+    if (max_level > kMaxLevels - 1) max_level = kMaxLevels - 1;
+    Slot& s = c->slots[slot];
+    const int top = pyramid_top_level(s.w, s.h, win_w, win_h, max_level);
+    rc = ensure_pyramid(c, slot, top);
+    if (rc) return rc;
+    if (out_levels) *out_levels = top;
+    return ICELK_OK;
+}
+
+// ---- tracker -----------------------------------------------------------------------------------
+int icelk_pyrlk(icelk_t* h, int prev_slot, int next_slot, const float* prev_xy, float* next_xy, uint8_t* status,
+                float* err, int n, int win_w, int win_h, int max_level, int crit_type, int max_count, double epsilon,
+                int flags, double min_eig_threshold)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = check_slot(c, prev_slot, true);
+    if (!rc) rc = check_slot(c, next_slot, true);
+    if (rc) return rc;
+    if (n < 0) FAIL(c, ICELK_EARG, "negative point count");
+    if (n > c->max_pts) FAIL(c, ICELK_ECAP, "more points than max_pts of icelk_create");
+    Slot& s0 = c->slots[prev_slot];
+    Slot& s1 = c->slots[next_slot];
+    if (s0.w != s1.w || s0.h != s1.h) FAIL(c, ICELK_EARG, "frame sizes differ");
+    LKParams P;
+    rc = make_lk_params(c, s0.w, s0.h, win_w, win_h, max_level, crit_type, max_count, epsilon, flags, min_eig_threshold,
+                        1.f, &P);
+    if (rc) return rc;
+    if (n == 0) return ICELK_OK;
+    if (!prev_xy || !next_xy) FAIL(c, ICELK_EARG, "null point buffer");
+    rc = ensure_pyramid(c, prev_slot, P.top_level);
+    if (!rc) rc = ensure_pyramid(c, next_slot, P.top_level);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_p0, prev_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    if (flags & ICELK_FLAG_INITIAL_FLOW)
+        HIPCHK(c, hipMemcpyAsync(c->d_p1, next_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    LKBuffers B{};
+    B.p_in = c->d_p0;
+    B.p_fwd = c->d_p1;
+    B.st_fwd = c->d_st_f;
+    B.err_fwd = c->d_err_f;
+    {
+        ProfScope p(c, K_LK);
+        rc = launch_lk(c->stream, pyramid_of(s0), pyramid_of(s1), B, n, P, false);
+    }
+    if (rc) FAIL(c, rc, "unsupported window size");
+    rc = check_launch(c, "lk");
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(next_xy, c->d_p1, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+    if (status) HIPCHK(c, hipMemcpyAsync(status, c->d_st_f, n, hipMemcpyDeviceToHost, c->stream));
+    if (err) HIPCHK(c, hipMemcpyAsync(err, c->d_err_f, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICELK_OK;
+}
+
+int icelk_track_fb(icelk_t* h, int slot0, int slot1, const float* p0, int n, int win_w, int win_h, int max_level,
+                   int crit_type, int max_count, double epsilon, double min_eig_threshold, float fb_threshold,
+                   float* p1, float* p0r, uint8_t* st_fwd, uint8_t* st_bwd, float* err_fwd, float* err_bwd, float* dist,
+                   uint8_t* valid)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = check_slot(c, slot0, true);
+    if (!rc) rc = check_slot(c, slot1, true);
+    if (rc) return rc;
+    if (n < 0) FAIL(c, ICELK_EARG, "negative point count");
+    if (n > c->max_pts) FAIL(c, ICELK_ECAP, "more points than max_pts of icelk_create");
+    Slot& s0 = c->slots[slot0];
+    Slot& s1 = c->slots[slot1];
+    if (s0.w != s1.w || s0.h != s1.h) FAIL(c, ICELK_EARG, "frame sizes differ");
+    LKParams P;
+    rc = make_lk_params(c, s0.w, s0.h, win_w, win_h, max_level, crit_type, max_count, epsilon, 0, min_eig_threshold,
+                        fb_threshold, &P);
+    if (rc) return rc;
+    if (n == 0) return ICELK_OK;
+    if (!p0) FAIL(c, ICELK_EARG, "null point buffer");
+    rc = ensure_pyramid(c, slot0, P.top_level);
+    if (!rc) rc = ensure_pyramid(c, slot1, P.top_level);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_p0, p0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    LKBuffers B{};
+    B.p_in = c->d_p0;
+    B.p_fwd = c->d_p1;
+    B.st_fwd = c->d_st_f;
+    B.err_fwd = c->d_err_f;
+    B.p_bwd = c->d_p0r;
+    B.st_bwd = c->d_st_b;
+    B.err_bwd = c->d_err_b;
+    B.dist = c->d_dist;
+    B.valid = c->d_valid;
+    {
+        ProfScope p(c, K_LK_FB);
+        rc = launch_lk(c->stream, pyramid_of(s0), pyramid_of(s1), B, n, P, true);
+    }
+    if (rc) FAIL(c, rc, "unsupported window size");
+    rc = check_launch(c, "lk_fb");
+    if (rc) return rc;
+    const size_t fb = sizeof(float) * n;
+    if (p1) HIPCHK(c, hipMemcpyAsync(p1, c->d_p1, 2 * fb, hipMemcpyDeviceToHost, c->stream));
+    if (p0r) HIPCHK(c, hipMemcpyAsync(p0r, c->d_p0r, 2 * fb, hipMemcpyDeviceToHost, c->stream));
+    if (st_fwd) HIPCHK(c, hipMemcpyAsync(st_fwd, c->d_st_f, n, hipMemcpyDeviceToHost, c->stream));
+    if (st_bwd) HIPCHK(c, hipMemcpyAsync(st_bwd, c->d_st_b, n, hipMemcpyDeviceToHost, c->stream));
+    if (err_fwd) HIPCHK(c, hipMemcpyAsync(err_fwd, c->d_err_f, fb, hipMemcpyDeviceToHost, c->stream));
+    if (err_bwd) HIPCHK(c, hipMemcpyAsync(err_bwd, c->d_err_b, fb, hipMemcpyDeviceToHost, c->stream));
+    if (dist) HIPCHK(c, hipMemcpyAsync(dist, c->d_dist, fb, hipMemcpyDeviceToHost, c->stream));
+    if (valid) HIPCHK(c, hipMemcpyAsync(valid, c->d_valid, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICELK_OK;
+}
+
+// ---- detector ----------------------------------------------------------------------------------
+int icelk_set_mask(icelk_t* h, const uint8_t* host_mask, int w, int h_, int stride)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!host_mask) {
+        c->has_mask = false;
+        return ICELK_OK;
+    }
+    if (w <= 0 || h_ <= 0 || stride < w) FAIL(c, ICELK_EARG, "bad mask");
+    if (w > c->max_w || h_ > c->max_h) FAIL(c, ICELK_ECAP, "mask larger than max_w x max_h");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->d_mask, c->mask_pitch, host_mask, stride, w, h_, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->has_mask = true;
+    c->mask_w = w;
+    c->mask_h = h_;
+    return ICELK_OK;
+}
+
+int icelk_min_eig_map(icelk_t* h, int slot, int block_size, float* host_out, int stride_elems)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = check_slot(c, slot, true);
+    if (rc) return rc;
+    Slot& s = c->slots[slot];
+    if (!host_out || stride_elems < s.w || block_size <= 0) FAIL(c, ICELK_EARG, "bad argument");
+    if (min_eig_lds_bytes(block_size) > 150 * 1024) FAIL(c, ICELK_EARG, "blockSize too large");
+    rc = wait_slot(c, slot);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->D.max_key, 0, sizeof(unsigned), c->stream));
+    {
+        ProfScope p(c, K_EIG);
+        launch_min_eig(c->stream, s.lv[0], block_size, c->D.eig, nullptr, 0, c->D.max_key);
+    }
+    rc = check_launch(c, "min_eig");
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy2DAsync(host_out, sizeof(float) * stride_elems, c->D.eig, sizeof(float) * s.w, sizeof(float) * s.w,
+                               s.h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICELK_OK;
+}
+
+int icelk_good_features(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level, double min_distance,
+                        int block_size, float* out_xy, int cap, int* out_n)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!out_n || cap < 0 || (cap > 0 && !out_xy)) FAIL(c, ICELK_EARG, "bad output buffer");
+    int n = 0;
+    int rc = detect_core(c, slot, use_mask, max_corners, quality_level, min_distance, block_size, cap, &n);
+    if (rc) return rc;
+    if (n > 0) {
+        HIPCHK(c, hipMemcpyAsync(out_xy, c->d_corners, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    *out_n = n;
+    return ICELK_OK;
+}
+
+// ---- segment state -----------------------------------------------------------------------------
+int icelk_seg_detect(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level, double min_distance,
+                     int block_size, int* out_n)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    int n = 0;
+    int rc = detect_core(c, slot, use_mask, max_corners, quality_level, min_distance, block_size, c->max_pts, &n);
+    if (rc) return rc;
+    launch_seg_init(c->stream, c->d_corners, n, c->d_live[0], c->d_origin[0], c->d_tracks, kMaxVert, c->d_nlive,
+                    c->d_tracked);
+    rc = check_launch(c, "seg_init");
+    if (rc) return rc;
+    c->seg_cur = 0;
+    c->seg_vert = 1;
+    c->seg_upper = n;
+    c->seg_active = true;
+    if (out_n) *out_n = n;
+    return ICELK_OK;
+}
+
+int icelk_seg_track_async(icelk_t* h, int slot_prev, int slot_next, int win_w, int win_h, int max_level, int crit_type,
+                          int max_count, double epsilon, double min_eig_threshold, float fb_threshold)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    return seg_track_core(c, slot_prev, slot_next, win_w, win_h, max_level, crit_type, max_count, epsilon,
+                          min_eig_threshold, fb_threshold);
+}
+
+int icelk_seg_live(icelk_t* h, int* out_live, int64_t* out_tracked_total)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->seg_active) FAIL(c, ICELK_ESTATE, "icelk_seg_detect has not been called");
+    int n = 0;
+    unsigned long long t = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, c->d_nlive + c->seg_cur, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&t, c->d_tracked, sizeof(t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->seg_upper = n;
+    if (out_live) *out_live = n;
+    if (out_tracked_total) *out_tracked_total = (int64_t)t;
+    return ICELK_OK;
+}
+
+int icelk_seg_track(icelk_t* h, int slot_prev, int slot_next, int win_w, int win_h, int max_level, int crit_type,
+                    int max_count, double epsilon, double min_eig_threshold, float fb_threshold, int* out_live)
+{
+    int rc = icelk_seg_track_async(h, slot_prev, slot_next, win_w, win_h, max_level, crit_type, max_count, epsilon,
+                                   min_eig_threshold, fb_threshold);
+    if (rc) return rc;
+    return icelk_seg_live(h, out_live, nullptr);
+}
+
+int icelk_seg_read(icelk_t* h, float* tracks, float* quality, int cap, int max_vertices, int* out_n, int* out_vertices)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->seg_active) FAIL(c, ICELK_ESTATE, "icelk_seg_detect has not been called");
+    int n = 0;
+    int rc = icelk_seg_live(h, &n, nullptr);
+    if (rc) return rc;
+    const int nv = c->seg_vert;
+    if (out_n) *out_n = n;
+    if (out_vertices) *out_vertices = nv;
+    if (!tracks && !quality) return ICELK_OK;
+    if (n > cap || nv > max_vertices) FAIL(c, ICELK_ECAP, "host track buffers too small");
+    if (n == 0) return ICELK_OK;
+    launch_seg_gather(c->stream, c->d_origin[c->seg_cur], c->d_nlive + c->seg_cur, n, c->d_tracks, c->d_quality, nv,
+                      kMaxVert, c->d_out_tracks, c->d_out_quality);
+    rc = check_launch(c, "seg_gather");
+    if (rc) return rc;
+    // host layout: (n, max_vertices, 2) and (n, max_vertices-1) with the caller's vertex dimension
+    if (tracks)
+        HIPCHK(c, hipMemcpy2DAsync(tracks, sizeof(float) * 2 * max_vertices, c->d_out_tracks, sizeof(float) * 2 * nv,
+                                   sizeof(float) * 2 * nv, n, hipMemcpyDeviceToHost, c->stream));
+    if (quality && nv > 1)
+        HIPCHK(c, hipMemcpy2DAsync(quality, sizeof(float) * (max_vertices - 1), c->d_out_quality, sizeof(float) * (nv - 1),
+                                   sizeof(float) * (nv - 1), n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICELK_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------------
+int icelk_prof_enable(icelk_t* h, int on)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    if (!on) prof_drain(c);
+    c->prof = on != 0;
+    return ICELK_OK;
+}
+
+int icelk_prof_reset(icelk_t* h)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    prof_drain(c);
+    for (int i = 0; i < K_COUNT_; i++) {
+        c->prof_launches[i] = 0;
+        c->prof_ms[i] = 0;
+    }
+    return ICELK_OK;
+}
+
+int icelk_prof_count(void) { return K_COUNT_; }
+
+const char* icelk_prof_name(int kernel_id)
+{
+    if (kernel_id < 0 || kernel_id >= K_COUNT_) return "";
+    return kKernelNames[kernel_id];
+}
+
+int icelk_prof_get(icelk_t* h, int kernel_id, int* launches, double* total_ms)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    if (kernel_id < 0 || kernel_id >= K_COUNT_) FAIL(c, ICELK_EARG, "bad kernel id");
+    prof_drain(c);
+    if (launches) *launches = c->prof_launches[kernel_id];
+    if (total_ms) *total_ms = c->prof_ms[kernel_id];
+    return ICELK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// icelk_internal.h -- shared between the translation units of libicelk.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/icelk.h"
+
+namespace icelk {
+
+constexpr int kMaxLevels = ICELK_MAX_LEVELS;
+constexpr int kPitchAlign = 64;  // bytes; every level row starts 64-B aligned (dword / dwordx4 loads)
+
+// One pyramid level in device memory (unpadded; borders are reflected inside the kernels).
+struct Level {
+    uint8_t* ptr;
+    int w, h, pitch;
+};
+
+// By-value kernel argument: the whole pyramid of one frame.
+struct Pyramid {
+    Level lv[kMaxLevels];
+};
+
+struct LKParams {
+    int win_w, win_h;
+    int top_level;      // effective maxLevel (levels used = top_level + 1)
+    int max_count;      // clamped criteria.maxCount
+    double eps2;        // clamped criteria.epsilon squared
+    int flags;
+    float min_eig_thr;
+    float fb_thr;
+    int margin;         // search-region margin R of the LDS-staged J tile
+};
+
+// kernel ids for the profiling table
+enum KernelId {
+    K_GRAY = 0,
+    K_PYRDOWN,
+    K_LK,
+    K_LK_FB,
+    K_EIG,
+    K_NMS,
+    K_CELLS,
+    K_SUPPRESS,
+    K_EMIT,
+    K_COMPACT,
+    K_SYNTH,
+    K_COUNT_
+};
+
+struct Slot {
+    uint8_t* base = nullptr;  // one allocation holding all levels
+    size_t bytes = 0;
+    int w = 0, h = 0;
+    int levels_built = 0;     // number of valid images (0 = empty, 1 = level 0 only)
+    Level lv[kMaxLevels];
+    hipEvent_t ready = nullptr;   // upload-complete event (async uploads)
+    bool pending = false;
+};
+
+struct ProfEvt {
+    hipEvent_t a, b;
+    int id;
+};
+
+struct Ctx;  // full definition in icelk_abi.hip
+
+// ---- launchers (each defined in its kernel TU) -------------------------------------------------
+void launch_bgr2gray(hipStream_t s, const uint8_t* src, int src_pitch, uint8_t* dst, int dst_pitch,
+                     int w, int h, int variant);
+void launch_pyrdown(hipStream_t s, const Level& src, const Level& dst);
+void launch_synth(hipStream_t s, const Level& dst, int64_t ux, int64_t uy, uint32_t seed);
+
+// LK.  p_in/p_out etc. are device pointers.  fb = fused forward+backward.
+struct LKBuffers {
+    const float* p_in;   // (n,2)
+    float* p_fwd;        // (n,2) forward result (in/out when INITIAL_FLOW)
+    uint8_t* st_fwd;
+    float* err_fwd;
+    float* p_bwd;        // fb only
+    uint8_t* st_bwd;
+    float* err_bwd;
+    float* dist;
+    uint8_t* valid;
+    const int* n_dev;    // optional device-side count (overrides n when non-null)
+};
+size_t lk_lds_bytes(const LKParams& P);
+int launch_lk(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
+              bool fb);
+
+// Detector stages.
+struct DetectScratch {
+    float* eig;            // w*h
+    unsigned* max_key;     // 1 (order-preserving key of the masked maximum)
+    unsigned long long* cand;   // candidate keys (value bits << 32 | raster index)
+    int* cand_count;       // 1
+    int cand_cap;
+    int* cell_count;       // grid cells + 1
+    int* cell_start;       // grid cells + 1
+    int* cell_fill;        // grid cells
+    unsigned long long* cell_cand;  // candidates grouped by cell
+    uint8_t* state;        // per grouped candidate: 0 undecided, 1 accepted, 2 rejected
+    int* undecided;        // 1
+    unsigned long long* acc;   // accepted keys
+    unsigned long long* acc_sorted;
+    int* acc_count;        // 1
+    void* sort_tmp;
+    size_t sort_tmp_bytes;
+};
+void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig, const uint8_t* mask,
+                    int mask_pitch, unsigned* max_key);
+void launch_nms_collect(hipStream_t s, const float* eig, int w, int h, const uint8_t* mask, int mask_pitch,
+                        const unsigned* max_key, double quality, unsigned long long* cand, int* cand_count,
+                        int cand_cap);
+// greedy min-distance suppression on the device; returns via acc/acc_count (unsorted)
+int run_min_distance(hipStream_t s, DetectScratch& D, int w, int h, int n_cand, double min_distance,
+                     std::string& err);
+size_t sort_tmp_bytes(int n);
+void sort_keys_desc(hipStream_t s, DetectScratch& D, const unsigned long long* in, unsigned long long* out,
+                    int n);
+void launch_emit_corners(hipStream_t s, const unsigned long long* keys, int n, int w, float* xy);
+
+// Segment bookkeeping (k_tracks.hip): stable compaction of survivors + track-table append.
+void launch_seg_init(hipStream_t s, const float* corners, int n, float* live_xy, int* origin, float* tracks,
+                     int max_vert, int* n_live, unsigned long long* tracked_total);
+void launch_compact(hipStream_t s, const float* p1, const float* dist, const uint8_t* valid, const int* origin_in,
+                    const int* n_in, float* live_out, int* origin_out, int* n_out, float* tracks, float* quality,
+                    int vert, int max_vert, unsigned long long* tracked_total);
+void launch_seg_gather(hipStream_t s, const int* origin, const int* n_live, int n_upper, const float* tracks,
+                       const float* quality, int nvert, int max_vert, float* out_tracks, float* out_quality);
+size_t min_eig_lds_bytes(int block_size);
+
+}  // namespace icelk

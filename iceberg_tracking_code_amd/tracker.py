@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference's tracking loops, driving the HIP library.
+
+Two forms of the same loop (s1_lucaskanade_tracking.py:304-450, s0_1_test_lucaskanade_tracking.py:77-181):
+
+* `run_reference_loop` -- the loop written against the cv2-shaped functions (api.py), list-of-lists
+  state exactly as in the reference.  Used by the parity tests and as the plumbing path of
+  BASELINE.json configs[0].
+* `SegmentTracker` -- the same semantics with the state resident on the GPU (slots, pyramids, live
+  points, track table); one pyramid build per frame instead of the four OpenCV does, one fused
+  forward+backward launch per pair, nothing crossing PCIe except the finished segment.
+
+Also here: the `.npz` wire format consumed by s2_cam_to_utm.py:177,197-198,233-234.
+"""
+import datetime as dt
+import os
+
+import numpy as np
+
+from . import api
+from .context import Context, TERM_CRITERIA_COUNT, TERM_CRITERIA_EPS
+
+# parameter literals of the reference (s1:240-248, s0_1:37-45)
+REF_FEATURE_PARAMS = dict(maxCorners=50000000, qualityLevel=0.007, minDistance=10, blockSize=10)
+REF_LK_PARAMS = dict(winSize=(35, 35), maxLevel=4, criteria=(TERM_CRITERIA_EPS | TERM_CRITERIA_COUNT, 25, 0.03))
+REF_FB_THRESHOLD = 1.0   # `valid = dist < 1` (s1:333), `self.distthreshold = 1.0` (s0_1:51)
+
+
+def npz_name(first_image_path, track_len, track_len_sec):
+    """'<%Y%m%d-%H%M%S>_{T*dt}sec_at_{dt}sec_tracks.npz' next to the image (s1:394)."""
+    return "{}_{}sec_at_{}sec_tracks.npz".format(str(first_image_path).split(".")[0], track_len * track_len_sec,
+                                                 track_len_sec)
+
+
+def segment_time_ok(names, track_len_sec):
+    """The +-2 s gap rule of s1:364-388 over the file names of one segment's frames."""
+    times = [dt.datetime.strptime(os.path.basename(str(n)), "%Y%m%d-%H%M%S.jpg") for n in names]
+    for a, b in zip(times[:-1], times[1:]):
+        if (b - a).seconds not in (track_len_sec - 2, track_len_sec - 1, track_len_sec, track_len_sec + 1,
+                                   track_len_sec + 2):
+            return False
+    return True
+
+
+def save_tracks(npzname, tracks, trackquality):
+    """np.savez(npzname, tracks=tracks, trackquality=trackquality) (s1:395)."""
+    np.savez(npzname, tracks=tracks, trackquality=trackquality)
+
+
+def run_reference_loop(frames, track_len, feature_params=None, lk_params=None, mask=None, cv=api,
+                       fb_threshold=REF_FB_THRESHOLD, on_segment=None):
+    """The frame loop of s1:307-450 over in-memory gray frames, against a cv2-shaped module `cv`.
+
+    Returns a list of (first_frame_index, tracks, trackquality) per completed segment, where tracks and
+    trackquality are the Python lists the reference would hand to np.savez.
+    """
+    feature_params = dict(REF_FEATURE_PARAMS if feature_params is None else feature_params)
+    lk_params = dict(REF_LK_PARAMS if lk_params is None else lk_params)
+    tracks, trackquality = [], []
+    segments = []
+    prev_gray = None
+    seg_first = 0
+    for counter, frame_gray in enumerate(frames):
+        if len(tracks) > 0:
+            img0, img1 = prev_gray, frame_gray
+            p0 = np.float32([tr[-1] for tr in tracks]).reshape(-1, 1, 2)
+            p1, st, err = cv.calcOpticalFlowPyrLK(img0, img1, p0, None, **lk_params)
+            p0r, st, err = cv.calcOpticalFlowPyrLK(img1, img0, p1, None, **lk_params)
+            diff = abs(p0 - p0r).reshape(-1, 2)
+            dist = np.sqrt(diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1], dtype=np.float32)
+            valid = dist < fb_threshold
+            new_tracks, new_quality = [], []
+            for tr, (x, y), ok, trq, d in zip(tracks, p1.reshape(-1, 2), valid, trackquality, dist):
+                if ok:
+                    tr.append((x, y))
+                    trq.append(d)
+                    if (len(tr) - 1) > track_len:
+                        del tr[0]
+                    new_tracks.append(tr)
+                    new_quality.append(trq)
+            tracks, trackquality = new_tracks, new_quality
+        if counter % track_len == 0:
+            if counter > 0:
+                seg = (seg_first, tracks, trackquality)
+                segments.append(seg)
+                if on_segment is not None:
+                    on_segment(*seg)
+            p = cv.goodFeaturesToTrack(frame_gray, mask=mask, **feature_params)
+            tracks, trackquality = [], []
+            seg_first = counter
+            if p is not None:
+                for x, y in np.float32(p).reshape(-1, 2):
+                    tracks.append([(x, y)])
+                    trackquality.append([])
+        prev_gray = frame_gray
+    return segments
+
+
+class LucasKanade:
+    """s0_1_test_lucaskanade_tracking.py:29-181 without the plotting: same constructor meaning
+    (detect_interval, time_spacing), same parameter literals, frames given in memory."""
+
+    def __init__(self, frames, detect_interval, time_spacing=60, cv=api, feature_params=None, lk_params=None):
+        self.detect_interval = detect_interval
+        self.time_spacing = time_spacing
+        self.feature_params = dict(REF_FEATURE_PARAMS if feature_params is None else feature_params)
+        self.lk_params = dict(REF_LK_PARAMS if lk_params is None else lk_params)
+        self.track_len = self.detect_interval
+        self.tracks = []
+        self.frames = frames
+        self.distthreshold = 1.0
+        self.cv = cv
+        self.track_counts = []   # what the reference prints at s0_1:129
+
+    def run(self):
+        cv = self.cv
+        mask = np.zeros_like(self.frames[0])
+        mask[:] = 255
+        for counter, frame_gray in enumerate(self.frames):
+            if len(self.tracks) > 0:
+                img0, img1 = self.prev_gray, frame_gray
+                p0 = np.float32([tr[-1] for tr in self.tracks]).reshape(-1, 1, 2)
+                p1, st, err = cv.calcOpticalFlowPyrLK(img0, img1, p0, None, **self.lk_params)
+                p0r, st, err = cv.calcOpticalFlowPyrLK(img1, img0, p1, None, **self.lk_params)
+                diff = abs(p0 - p0r).reshape(-1, 2)
+                dist = (diff[:, 0] ** 2 + diff[:, 1] ** 2) ** 0.5
+                good = dist < self.distthreshold
+                new_tracks = []
+                for tr, (x, y), good_flag in zip(self.tracks, p1.reshape(-1, 2), good):
+                    if good_flag == 1:
+                        tr.append((x, y))
+                        if (len(tr) - 1) > self.track_len:
+                            del tr[0]
+                        new_tracks.append(tr)
+                self.tracks = new_tracks
+            if counter % self.detect_interval == 0:
+                self.track_counts.append(len(self.tracks))
+                p = cv.goodFeaturesToTrack(frame_gray, mask=mask, **self.feature_params)
+                self.tracks = []
+                if p is not None:
+                    for x, y in np.float32(p).reshape(-1, 2):
+                        self.tracks.append([(x, y)])
+            self.prev_gray = frame_gray
+        return self.tracks
+
+
+class SegmentTracker:
+    """Device-resident form of the s1 loop.  Feed frames one at a time; finished segments come back as
+    (first_frame_index, tracks (n, T+1, 2) f32, trackquality (n, T) f32) -- the np.savez payload.
+
+    Frames are given as host arrays (`push`), as device pointers (`push_device`) or generated on the
+    device (`push_synth`).  Three slots rotate: previous frame, current frame, and one being uploaded.
+    """
+
+    def __init__(self, width, height, track_len, feature_params=None, lk_params=None, mask=None, max_pts=1 << 18,
+                 device=0, fb_threshold=REF_FB_THRESHOLD, ctx=None, n_slots=3):
+        self.track_len = int(track_len)
+        if self.track_len < 1 or self.track_len > 16:
+            raise ValueError("track_len must be in 1..16")
+        self.fp = dict(REF_FEATURE_PARAMS if feature_params is None else feature_params)
+        self.lk = dict(REF_LK_PARAMS if lk_params is None else lk_params)
+        self.fb_threshold = float(fb_threshold)
+        self.w, self.h = width, height
+        self.ctx = ctx if ctx is not None else Context(width, height, n_slots=n_slots, max_pts=max_pts, device=device)
+        self.n_slots = self.ctx.n_slots
+        self.use_mask = mask is not None
+        if self.use_mask:
+            self.ctx.set_mask(mask)
+        self.counter = 0          # frames consumed
+        self.cur = -1             # slot of the newest frame
+        self.seg_first = 0
+        self.active = False
+        self.n_detected = 0
+
+    # -- frame sources --------------------------------------------------------------------------
+    def _next_slot(self):
+        return (self.cur + 1) % self.n_slots
+
+    def push(self, frame_gray, wait=True):
+        s = self._next_slot()
+        self.ctx.upload_gray(s, frame_gray)
+        return self._step(s, wait)
+
+    def push_bgr(self, frame, wait=True, variant=3):
+        s = self._next_slot()
+        self.ctx.upload_bgr(s, frame, variant)
+        return self._step(s, wait)
+
+    def push_device(self, dev_ptr, stride, wait=True):
+        s = self._next_slot()
+        self.ctx.set_gray_device(s, dev_ptr, self.w, self.h, stride)
+        return self._step(s, wait)
+
+    def push_pinned(self, pinned_ptr, stride, wait=True):
+        s = self._next_slot()
+        self.ctx.upload_gray_async(s, pinned_ptr, self.w, self.h, stride)
+        return self._step(s, wait)
+
+    def push_synth(self, ux, uy, seed=1234, wait=True):
+        s = self._next_slot()
+        self.ctx.synth_frame(s, self.w, self.h, ux, uy, seed)
+        return self._step(s, wait)
+
+    # -- the loop body (s1:313-450) -------------------------------------------------------------
+    def _step(self, slot, wait):
+        out = None
+        prev = self.cur
+        if self.active:
+            self.ctx.seg_track(prev, slot, self.lk["winSize"], self.lk["maxLevel"], self.lk["criteria"],
+                               self.lk.get("minEigThreshold", 1e-4), self.fb_threshold, wait=False)
+        if self.counter % self.track_len == 0:
+            if self.counter > 0 and wait:
+                tracks, quality = self.ctx.seg_read()
+                out = (self.seg_first, tracks, quality)
+            self.n_detected = self.ctx.seg_detect(slot, self.fp["maxCorners"], self.fp["qualityLevel"],
+                                                  self.fp["minDistance"], self.use_mask, self.fp.get("blockSize", 3))
+            self.active = True
+            self.seg_first = self.counter
+        self.cur = slot
+        self.counter += 1
+        return out
+
+    def live(self):
+        return self.ctx.seg_live()
+
+    def close(self):
+        self.ctx.close()

@@ -1,0 +1,142 @@
+/*
+ * icelk.h -- C ABI of the MI355X-native sparse Lucas-Kanade tracking library (libicelk.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of glacierbliss/iceberg_tracking_code: the
+ * per-frame loop of s1_lucaskanade_tracking.py:307-450 (twin: s0_1_test_lucaskanade_tracking.py:77-181).
+ * The reference has no FFI layer; the seam is three cv2 calls.  Each entry point below names the
+ * reference call site it replaces.  Plain C: pointers and sizes only, no C++/torch types, no exceptions.
+ *
+ * Conventions
+ *   - every function returns ICELK_OK (0) or a negative ICELK_E* code; icelk_last_error() gives text.
+ *   - the caller owns every host buffer; the library owns all device memory (frames, pyramids, points).
+ *   - a handle is bound to one GPU and one HIP stream and is not thread-safe; use one handle per
+ *     thread/process.  Multi-GPU = one process per GPU, one handle each (DESIGN.md "Multi-GPU").
+ *   - "slot" = a device-resident frame with its Gaussian pyramid.  Slots let the caller keep the
+ *     previous frame (prev_gray = frame_gray, s1:450) and its pyramid on the GPU instead of
+ *     rebuilding both pyramids in every cv2.calcOpticalFlowPyrLK call as OpenCV does.
+ *   - points are interleaved (x, y) float32, i.e. numpy (N,1,2) float32 as cv2 returns them.
+ *   - calls are synchronous with respect to their host outputs unless named *_async.
+ */
+#ifndef ICELK_H
+#define ICELK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct icelk_ctx icelk_t;
+
+#define ICELK_OK 0
+#define ICELK_EARG (-1)    /* bad argument                       -> Python ValueError   */
+#define ICELK_ENOMEM (-2)  /* host or device allocation failed   -> Python MemoryError  */
+#define ICELK_EHIP (-3)    /* HIP runtime error                  -> Python RuntimeError */
+#define ICELK_ECAP (-4)    /* exceeds the capacity given at icelk_create                */
+#define ICELK_ESTATE (-5)  /* slot empty / pyramid missing / segment not started        */
+
+/* cv2.TERM_CRITERIA_COUNT / cv2.TERM_CRITERIA_EPS (criteria tuple at s1:248) */
+#define ICELK_CRIT_COUNT 1
+#define ICELK_CRIT_EPS 2
+/* cv2.OPTFLOW_USE_INITIAL_FLOW / cv2.OPTFLOW_LK_GET_MIN_EIGENVALS */
+#define ICELK_FLAG_INITIAL_FLOW 4
+#define ICELK_FLAG_MIN_EIGENVALS 8
+/* fixed-point coefficient sets of cv2.cvtColor(COLOR_BGR2GRAY): OpenCV 3.x (14 bit), 4.x (15 bit) */
+#define ICELK_GRAY_CV3 3
+#define ICELK_GRAY_CV4 4
+
+#define ICELK_MAX_LEVELS 12 /* pyramid images per slot (maxLevel <= 11) */
+
+/* ---- library / handle ------------------------------------------------------------------- */
+int icelk_version(void);
+/* Text of the last error on this handle (or of the last failed icelk_create when h == NULL). */
+const char* icelk_last_error(icelk_t* h);
+/* One handle per GPU.  max_w/max_h bound the frame size, n_slots the resident frames,
+ * max_pts the features per call (maxCorners / len(tracks)). */
+int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, icelk_t** out);
+int icelk_destroy(icelk_t* h);
+/* Run all work on the caller's HIP stream (hipStream_t as void*; NULL = the handle's own stream). */
+int icelk_set_stream(icelk_t* h, void* hip_stream);
+int icelk_sync(icelk_t* h);
+
+/* ---- frame ingest: replaces cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY) at s1:283,311 / s0_1:71,80 */
+/* host 8-bit gray image -> slot (level 0); invalidates the slot's pyramid. */
+int icelk_upload_gray(icelk_t* h, int slot, const uint8_t* host, int w, int h_, int stride);
+/* host 8-bit 3-channel image -> gray in slot.  Channel 0 gets the "B" coefficient: feeding PIL's RGB
+ * arrays, as the reference does (s1:310-311), reproduces its swapped weights. */
+int icelk_upload_bgr(icelk_t* h, int slot, const uint8_t* host, int w, int h_, int stride, int gray_variant);
+/* same two, from device memory (e.g. a torch tensor's data_ptr) */
+int icelk_set_gray_device(icelk_t* h, int slot, const void* dev, int w, int h_, int stride);
+int icelk_cvt_bgr_device(icelk_t* h, int slot, const void* dev_bgr, int w, int h_, int stride, int gray_variant);
+/* asynchronous upload from PINNED host memory on the handle's copy stream (double-buffered
+ * streaming, BASELINE.json configs[2]); compute on `slot` waits for the copy by an event. */
+int icelk_upload_gray_async(icelk_t* h, int slot, const uint8_t* pinned_host, int w, int h_, int stride);
+int icelk_host_alloc(void** out, uint64_t bytes); /* pinned host memory for the call above */
+int icelk_host_free(void* p);
+/* procedural frame generated on the device (integer value noise, bit-identical to
+ * iceberg_tracking_code_amd/synth.py); ux,uy = shift in 1/256 px. */
+int icelk_synth_frame(icelk_t* h, int slot, int w, int h_, int64_t ux, int64_t uy, uint32_t seed);
+/* read back pyramid level `level` of a slot (level 0 = the gray frame). */
+int icelk_download_level(icelk_t* h, int slot, int level, uint8_t* host, int stride, int* w, int* h_);
+
+/* ---- pyramid: cv::buildOpticalFlowPyramid inside cv2.calcOpticalFlowPyrLK (s1:323,326) -------- */
+/* Builds levels 1..L of the slot, L = min(max_level, first level whose successor is <= winSize).
+ * *out_levels receives L.  icelk_pyrlk / icelk_track_fb call this themselves when needed. */
+int icelk_build_pyramid(icelk_t* h, int slot, int win_w, int win_h, int max_level, int* out_levels);
+
+/* ---- tracker: replaces cv2.calcOpticalFlowPyrLK(img0, img1, p0, None, **lk_params) s1:323,326 - */
+/* next_xy is an input as well when flags has ICELK_FLAG_INITIAL_FLOW.  n == 0 is not an error. */
+int icelk_pyrlk(icelk_t* h, int prev_slot, int next_slot, const float* prev_xy, float* next_xy,
+                uint8_t* status, float* err, int n, int win_w, int win_h, int max_level,
+                int crit_type, int max_count, double epsilon, int flags, double min_eig_threshold);
+/* Fused forward + backward + distance test of s1:323-333 (one launch, pyramids built once):
+ *   p1 = LK(slot0 -> slot1, p0);  p0r = LK(slot1 -> slot0, p1);
+ *   dist = sqrt(dx^2 + dy^2) of |p0 - p0r|;  valid = dist < fb_threshold.
+ * Any output pointer may be NULL. */
+int icelk_track_fb(icelk_t* h, int slot0, int slot1, const float* p0, int n, int win_w, int win_h,
+                   int max_level, int crit_type, int max_count, double epsilon, double min_eig_threshold,
+                   float fb_threshold, float* p1, float* p0r, uint8_t* st_fwd, uint8_t* st_bwd,
+                   float* err_fwd, float* err_bwd, float* dist, uint8_t* valid);
+
+/* ---- detector: replaces cv2.goodFeaturesToTrack(frame_gray, mask=mask, **feature_params) s1:437 */
+/* Mask (s1:285-294) is uploaded once and reused; NULL clears it. */
+int icelk_set_mask(icelk_t* h, const uint8_t* host_mask, int w, int h_, int stride);
+/* cornerMinEigenVal map of the slot (debug / parity). */
+int icelk_min_eig_map(icelk_t* h, int slot, int block_size, float* host_out, int stride_elems);
+/* Shi-Tomasi corners in response order.  max_corners <= 0 = unlimited (up to max_pts).
+ * *out_n == 0 corresponds to cv2 returning None (guarded at s1:445). */
+int icelk_good_features(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level,
+                        double min_distance, int block_size, float* out_xy, int cap, int* out_n);
+
+/* ---- device-resident segment state: the `tracks` / `trackquality` lists of s1:299-300,335-359 --
+ * A segment starts at a detection frame (counter % track_len == 0, s1:362,437-448) and is extended
+ * by one vertex per tracked frame; only tracks passing the forward-backward test survive, in order.
+ * Nothing crosses PCIe until icelk_seg_read. */
+int icelk_seg_detect(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level,
+                     double min_distance, int block_size, int* out_n);
+int icelk_seg_track(icelk_t* h, int slot_prev, int slot_next, int win_w, int win_h, int max_level,
+                    int crit_type, int max_count, double epsilon, double min_eig_threshold,
+                    float fb_threshold, int* out_live);
+/* tracks: (n, n_vertices, 2) float32; quality: (n, n_vertices-1) float32 -- the arrays np.savez
+ * writes at s1:394-395.  cap = rows available in the host buffers, max_vertices = their vertex
+ * dimension. */
+int icelk_seg_read(icelk_t* h, float* tracks, float* quality, int cap, int max_vertices, int* out_n,
+                   int* out_vertices);
+/* non-blocking variants for pipelined loops: no host read-back, counts stay on the device */
+int icelk_seg_track_async(icelk_t* h, int slot_prev, int slot_next, int win_w, int win_h, int max_level,
+                          int crit_type, int max_count, double epsilon, double min_eig_threshold,
+                          float fb_threshold);
+int icelk_seg_live(icelk_t* h, int* out_live, int64_t* out_tracked_total);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* Per-kernel HIP-event timing on the handle's stream (bench.py's roofline leg). */
+int icelk_prof_enable(icelk_t* h, int on);
+int icelk_prof_reset(icelk_t* h);
+int icelk_prof_count(void);
+const char* icelk_prof_name(int kernel_id);
+int icelk_prof_get(icelk_t* h, int kernel_id, int* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICELK_H */

@@ -1,0 +1,175 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle, bit-exact on the same seeded inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CRIT_DEFAULT = (3, 30, 0.01)
+CRIT_REF = (3, 25, 0.03)
+
+
+def _pair(synth, w, h, ux, uy, seed=1234):
+    return synth.frame(w, h, 0, 0, seed), synth.frame(w, h, ux, uy, seed)
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (641, 479), (37, 19), (4, 3), (1023, 5)])
+@pytest.mark.parametrize("variant", [3, 4])
+def test_gray(ctx, orc, w, h, variant):
+    rng = np.random.RandomState(w * 7 + h + variant)
+    img = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+    ctx.upload_bgr(0, img, variant)
+    got = ctx.download_level(0, 0)
+    assert np.array_equal(got, orc.bgr2gray(img, variant))
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (641, 479), (333, 257), (64, 48), (23, 31), (100, 8)])
+def test_pyramid(ctx, orc, synth, w, h):
+    rng = np.random.RandomState(w + 13 * h)
+    img = rng.randint(0, 256, size=(h, w)).astype(np.uint8)
+    ctx.upload_gray(0, img)
+    top = ctx.build_pyramid(0, (5, 5), 6)
+    ref = orc.build_pyramid(img, (5, 5), 6)
+    assert top == len(ref) - 1
+    for l, r in enumerate(ref):
+        got = ctx.download_level(0, l)
+        assert got.shape == r.shape
+        assert np.array_equal(got, r), "level %d differs" % l
+
+
+def test_pyramid_stop_rule(ctx, orc, synth):
+    img = synth.frame(640, 480)
+    ctx.upload_gray(0, img)
+    for win, ml in [((21, 21), 3), ((35, 35), 4), ((35, 35), 10), ((100, 100), 5), ((400, 400), 3)]:
+        assert ctx.build_pyramid(0, win, ml) == orc.pyramid_levels(640, 480, win, ml)
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (200, 100), (37, 29)])
+def test_synth_device_equals_numpy(ctx, synth, w, h):
+    for ux, uy, seed in [(0, 0, 1234), (300, -200, 1234), (-7777, 12345, 99)]:
+        ctx.synth_frame(1, w, h, ux, uy, seed)
+        assert np.array_equal(ctx.download_level(1, 0), synth.frame(w, h, ux, uy, seed))
+
+
+def _points(rng, n, w, h, border=-5.0):
+    return np.stack([rng.uniform(border, w - border, n), rng.uniform(border, h - border, n)], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("win,maxlevel,crit", [((21, 21), 3, CRIT_DEFAULT), ((35, 35), 4, CRIT_REF),
+                                                ((31, 31), 5, CRIT_DEFAULT), ((5, 7), 2, CRIT_DEFAULT),
+                                                ((15, 9), 0, (1, 5, 0.0)), ((11, 11), 3, (2, 0, 0.05)),
+                                                ((41, 41), 2, CRIT_REF), ((64, 64), 1, CRIT_REF)])
+def test_pyrlk_bit_exact(ctx, orc, synth, win, maxlevel, crit):
+    w, h = 640, 480
+    img0, img1 = _pair(synth, w, h, 410, -333)
+    rng = np.random.RandomState(win[0] * 100 + maxlevel)
+    # includes points near and beyond the borders (negative / > size coordinates)
+    pts = _points(rng, 700, w, h, border=-12.0)
+    ctx.upload_gray(0, img0)
+    ctx.upload_gray(1, img1)
+    p1, st, er = ctx.pyrlk(0, 1, pts, None, win, maxlevel, crit)
+    q1, qs, qe = orc.pyrlk(img0, img1, pts, None, win, maxlevel, crit)
+    assert np.array_equal(st, qs)
+    assert np.array_equal(p1.view(np.uint32), q1.view(np.uint32)), "nextPts differ: max |d| = %g" % np.abs(p1 - q1).max()
+    assert np.array_equal(er.view(np.uint32), qe.view(np.uint32))
+    assert st.sum() > 0.8 * len(pts)
+
+
+def test_pyrlk_flags(ctx, orc, synth):
+    w, h = 320, 240
+    img0, img1 = _pair(synth, w, h, -500, 250)
+    rng = np.random.RandomState(5)
+    pts = _points(rng, 300, w, h, 10.0)
+    guess = pts + np.float32([1.5, -0.5])
+    ctx.upload_gray(0, img0)
+    ctx.upload_gray(1, img1)
+    for flags in (4, 8, 12):
+        p1, st, er = ctx.pyrlk(0, 1, pts, guess, (21, 21), 3, CRIT_DEFAULT, flags)
+        q1, qs, qe = orc.pyrlk(img0, img1, pts, guess, (21, 21), 3, CRIT_DEFAULT, flags)
+        assert np.array_equal(st, qs)
+        assert np.array_equal(p1.view(np.uint32), q1.view(np.uint32))
+        assert np.array_equal(er.view(np.uint32), qe.view(np.uint32))
+
+
+def test_pyrlk_flat_and_outside(ctx, orc):
+    """status must go to 0 on texture-less patches (minEig test) and for points far outside."""
+    w, h = 200, 160
+    img = np.full((h, w), 77, np.uint8)
+    img[40:80, 50:120] = 200
+    pts = np.float32([[10, 10], [150, 140], [50, 40], [119, 79], [-100, -100], [500, 500], [85, 60]])
+    ctx.upload_gray(0, img)
+    ctx.upload_gray(1, img)
+    p1, st, er = ctx.pyrlk(0, 1, pts, None, (21, 21), 2, CRIT_DEFAULT)
+    q1, qs, qe = orc.pyrlk(img, img, pts, None, (21, 21), 2, CRIT_DEFAULT)
+    assert np.array_equal(st, qs) and np.array_equal(p1.view(np.uint32), q1.view(np.uint32))
+    assert np.array_equal(er.view(np.uint32), qe.view(np.uint32))
+    assert st.ravel()[4] == 0 and st.ravel()[5] == 0 and st.ravel()[0] == 0
+
+
+def test_pyrlk_empty(ctx, synth):
+    img = synth.frame(64, 48)
+    ctx.upload_gray(0, img)
+    ctx.upload_gray(1, img)
+    p1, st, er = ctx.pyrlk(0, 1, np.zeros((0, 1, 2), np.float32))
+    assert p1.shape == (0, 1, 2) and st.shape == (0, 1) and er.shape == (0, 1)
+
+
+@pytest.mark.parametrize("win,maxlevel,crit", [((21, 21), 3, CRIT_DEFAULT), ((35, 35), 4, CRIT_REF)])
+def test_track_fb_bit_exact(ctx, orc, synth, win, maxlevel, crit):
+    w, h = 640, 480
+    img0, img1 = _pair(synth, w, h, 600, 420)
+    pts = orc.good_features(img0, 1500, 0.01, 7, blockSize=5).reshape(-1, 2)
+    ctx.upload_gray(0, img0)
+    ctx.upload_gray(1, img1)
+    g = ctx.track_fb(0, 1, pts, win, maxlevel, crit)
+    r = orc.track_fb(img0, img1, pts, win, maxlevel, crit)
+    for k in ("p1", "p0r", "err_fwd", "err_bwd", "dist"):
+        assert np.array_equal(g[k].view(np.uint32), r[k].view(np.uint32)), k
+    for k in ("st_fwd", "st_bwd", "valid"):
+        assert np.array_equal(g[k], r[k]), k
+    flow = synth.true_flow((0, 0), (600, 420))
+    ok = g["valid"].astype(bool)
+    assert ok.mean() > 0.9
+    e = np.abs((g["p1"] - pts)[ok] - flow).max(axis=1)
+    assert np.median(e) < 0.05 and np.percentile(e, 95) < 0.15
+
+
+@pytest.mark.parametrize("bs", [3, 10, 5, 2])
+@pytest.mark.parametrize("w,h", [(640, 480), (131, 77)])
+def test_min_eig_map_bit_exact(ctx, orc, synth, w, h, bs):
+    img = synth.frame(w, h, 17, 4242, 7)
+    ctx.upload_gray(0, img)
+    got = ctx.min_eig_map(0, bs)
+    ref = orc.min_eig_map(img, bs)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), np.abs(got - ref).max()
+
+
+@pytest.mark.parametrize("maxc,q,md,bs", [(200, 0.01, 10, 3), (0, 0.007, 10, 10), (5000, 0.02, 3.5, 5),
+                                          (1000, 0.05, 0, 3), (0, 0.3, 1, 3), (10000, 0.01, 25, 7)])
+def test_good_features_exact(ctx, orc, synth, maxc, q, md, bs):
+    img = synth.frame(640, 480, 0, 0, 4321)
+    ctx.upload_gray(0, img)
+    got = ctx.good_features(0, maxc, q, md, False, bs)
+    ref = orc.good_features(img, maxc, q, md, None, bs)
+    assert got is not None and ref is not None
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)
+
+
+def test_good_features_mask_and_none(ctx, orc, synth):
+    img = synth.frame(640, 480, 0, 0, 4321)
+    mask = np.zeros_like(img)
+    mask[100:300, 200:500] = 255
+    ctx.upload_gray(0, img)
+    ctx.set_mask(mask)
+    got = ctx.good_features(0, 0, 0.01, 10, True, 10)
+    ref = orc.good_features(img, 0, 0.01, 10, mask, 10)
+    assert np.array_equal(got, ref)
+    xs, ys = got[:, 0, 0], got[:, 0, 1]
+    assert xs.min() >= 200 and xs.max() < 500 and ys.min() >= 100 and ys.max() < 300
+    flat = np.full((480, 640), 9, np.uint8)
+    ctx.upload_gray(0, flat)
+    assert ctx.good_features(0, 100, 0.01, 10, False, 3) is None
+    ctx.set_mask(np.zeros_like(img))
+    ctx.upload_gray(0, img)
+    assert ctx.good_features(0, 100, 0.01, 10, True, 3) is None
+    ctx.set_mask(None)
