@@ -35,6 +35,7 @@ SIGNATURES = {
     "icelk_host_alloc": (C.c_int, [C.POINTER(vp), C.c_uint64]),
     "icelk_host_free": (C.c_int, [vp]),
     "icelk_synth_frame": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_uint32]),
+    "icelk_drop_pyramid": (C.c_int, [handle_p, C.c_int]),
     "icelk_download_level": (C.c_int, [handle_p, C.c_int, C.c_int, u8p, C.c_int, i32p, i32p]),
     "icelk_build_pyramid": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_int, i32p]),
     "icelk_pyrlk": (C.c_int, [handle_p, C.c_int, C.c_int, f32p, f32p, u8p, f32p, C.c_int, C.c_int, C.c_int, C.c_int,

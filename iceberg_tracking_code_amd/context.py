@@ -104,6 +104,9 @@ class Context:
     def synth_frame(self, slot, w, h, ux=0, uy=0, seed=1234):
         self._ck(self._lib.icelk_synth_frame(self._h, slot, w, h, int(ux), int(uy), int(seed)))
 
+    def drop_pyramid(self, slot):
+        self._ck(self._lib.icelk_drop_pyramid(self._h, slot))
+
     def download_level(self, slot, level=0):
         w, h = C.c_int(0), C.c_int(0)
         self._ck(self._lib.icelk_download_level(self._h, slot, level, None, 0, C.byref(w), C.byref(h)))

@@ -659,6 +659,16 @@ int icelk_synth_frame(icelk_t* h, int slot, int w, int h_, int64_t ux, int64_t u
     return ICELK_OK;
 }
 
+int icelk_drop_pyramid(icelk_t* h, int slot)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    int rc = check_slot(c, slot, true);
+    if (rc) return rc;
+    c->slots[slot].levels_built = 1;
+    return ICELK_OK;
+}
+
 int icelk_download_level(icelk_t* h, int slot, int level, uint8_t* host, int stride, int* w, int* h_)
 {
     if (!h) return ICELK_EARG;

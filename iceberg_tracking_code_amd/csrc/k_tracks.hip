@@ -16,7 +16,7 @@ __global__ void k_seg_init(const float* __restrict__ corners, int n, float* __re
                            unsigned long long* tracked_total)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { *n_live = n; *tracked_total = 0ull; }
+    if (i == 0) *n_live = n;  // tracked_total keeps counting across segments
     if (i >= n) return;
     const float x = corners[2 * i], y = corners[2 * i + 1];
     live_xy[2 * i] = x; live_xy[2 * i + 1] = y;

@@ -195,6 +195,11 @@ class SegmentTracker:
         self.ctx.upload_gray_async(s, pinned_ptr, self.w, self.h, stride)
         return self._step(s, wait)
 
+    def push_slot(self, slot, wait=True):
+        """Use a frame that already sits in `slot` (level 0 resident in HBM); its pyramid is rebuilt."""
+        self.ctx.drop_pyramid(slot)
+        return self._step(slot, wait)
+
     def push_synth(self, ux, uy, seed=1234, wait=True):
         s = self._next_slot()
         self.ctx.synth_frame(s, self.w, self.h, ux, uy, seed)

@@ -76,6 +76,9 @@ int icelk_host_free(void* p);
 /* procedural frame generated on the device (integer value noise, bit-identical to
  * iceberg_tracking_code_amd/synth.py); ux,uy = shift in 1/256 px. */
 int icelk_synth_frame(icelk_t* h, int slot, int w, int h_, int64_t ux, int64_t uy, uint32_t seed);
+/* Forget levels >= 1 of a slot whose level 0 stays resident, so the next tracker call rebuilds the
+ * pyramid (a frame that is already in HBM re-enters the loop without a copy). */
+int icelk_drop_pyramid(icelk_t* h, int slot);
 /* read back pyramid level `level` of a slot (level 0 = the gray frame). */
 int icelk_download_level(icelk_t* h, int slot, int level, uint8_t* host, int stride, int* w, int* h_);
 

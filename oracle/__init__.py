@@ -10,6 +10,6 @@ of icelk_oracle.c.
 """
 from .cpu import (  # noqa: F401
     CRIT_COUNT, CRIT_EPS, FLAG_INITIAL_FLOW, FLAG_MIN_EIGENVALS,
-    build, lib, set_threads, bgr2gray, pyrdown, pyramid_levels, build_pyramid, scharr,
+    build, lib, set_threads, lk_stats, bgr2gray, pyrdown, pyramid_levels, build_pyramid, scharr,
     pyrlk, track_fb, min_eig_map, good_features,
 )

@@ -28,7 +28,7 @@ def build(force=False):
     """Compile the C restatement with the committed Makefile (gcc only)."""
     src = os.path.join(_HERE, "icelk_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
 
@@ -72,6 +72,13 @@ def _chk(rc):
     if rc < 0:
         raise RuntimeError("oracle error %d" % rc)
     return rc
+
+
+def lk_stats(reset=True):
+    """(template patches built, LK iterations, calls) since the last reset."""
+    out = (C.c_longlong * 3)()
+    lib().orc_lk_stats(out, 1 if reset else 0)
+    return tuple(int(v) for v in out)
 
 
 def set_threads(n):

@@ -268,6 +268,14 @@ int orc_build_pyramid(const uint8_t* img, int w, int h, int stride, int win_w, i
  * ---------------------------------------------------------------------------------------- */
 #define W_BITS 14
 
+/* work counters of the last orc_pyrlk calls (ops accounting in DESIGN.md): [0] template patches
+ * built (point x level visits that pass the bounds test), [1] LK iterations, [2] calls */
+static long long g_lk_stats[3];
+void orc_lk_stats(long long* out, int reset)
+{
+    for (int i = 0; i < 3; i++) { out[i] = g_lk_stats[i]; if (reset) g_lk_stats[i] = 0; }
+}
+
 static void bilinear_weights(float a, float b, int* w00, int* w01, int* w10, int* w11)
 {
     *w00 = round_half_even((1.f - a) * (1.f - b) * (1 << W_BITS));
@@ -312,6 +320,7 @@ int orc_pyrlk(const uint8_t* prev, int prev_stride, const uint8_t* next, int nex
     int16_t* dbuf = (int16_t*)malloc(sizeof(int16_t) * 2 * dpw0 * ((size_t)pI[0].h + 2 * win_h));
     if (!dbuf) { free_pyramid(pI, nI); free_pyramid(pJ, nJ); return ORC_ENOMEM; }
 
+    long long n_patches = 0, n_iters = 0;
     for (int level = eff_level; level >= 0; level--) {
         const orc_level* LI = &pI[level];
         const orc_level* LJ = &pJ[level];
@@ -326,7 +335,7 @@ int orc_pyrlk(const uint8_t* prev, int prev_stride, const uint8_t* next, int nex
         {
             int16_t* Iwin = (int16_t*)malloc(sizeof(int16_t) * 3 * (size_t)win_w * win_h);
             int16_t* dIwin = Iwin + (size_t)win_w * win_h;
-#pragma omp for schedule(dynamic, 64)
+#pragma omp for schedule(dynamic, 64) reduction(+ : n_patches, n_iters)
             for (int pt = 0; pt < n; pt++) {
                 float px = prev_pts[2 * pt] * (float)(1. / (1 << level));
                 float py = prev_pts[2 * pt + 1] * (float)(1. / (1 << level));
@@ -353,6 +362,7 @@ int orc_pyrlk(const uint8_t* prev, int prev_stride, const uint8_t* next, int nex
                 int iw00, iw01, iw10, iw11;
                 bilinear_weights(a, b, &iw00, &iw01, &iw10, &iw11);
 
+                n_patches++;
                 int64_t iA11 = 0, iA12 = 0, iA22 = 0;
                 for (int y = 0; y < win_h; y++) {
                     const uint8_t* src = LI->img + (ptrdiff_t)(y + ipy) * stepI + ipx;
@@ -394,6 +404,7 @@ int orc_pyrlk(const uint8_t* prev, int prev_stride, const uint8_t* next, int nex
                         if (level == 0) status[pt] = 0;
                         break;
                     }
+                    n_iters++;
                     a = nx - inx; b = ny - iny;
                     bilinear_weights(a, b, &iw00, &iw01, &iw10, &iw11);
                     int64_t ib1 = 0, ib2 = 0;
@@ -449,6 +460,9 @@ int orc_pyrlk(const uint8_t* prev, int prev_stride, const uint8_t* next, int nex
             free(Iwin);
         }
     }
+    g_lk_stats[0] += n_patches;
+    g_lk_stats[1] += n_iters;
+    g_lk_stats[2] += 1;
     free(dbuf);
     free_pyramid(pI, nI);
     free_pyramid(pJ, nJ);
