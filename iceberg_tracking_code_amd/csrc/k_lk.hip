@@ -21,55 +21,16 @@
 //     to the CPU oracle.
 //   * A workgroup is one wave (64 threads): barriers are free, divergent iteration counts cost
 //     only that wave's tail, and up to 32 features are resident per CU.
-#include "icelk_internal.h"
+#include "lk_common.h"
 
 namespace icelk {
 
+bool launch_lk_fast(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
+                    bool fb);  // k_lk_fast.hip
+
 namespace {
 
-constexpr int W_BITS = 14;
-
-__device__ __forceinline__ int reflect101(int p, int n)
-{
-    if (n == 1) return 0;
-    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
-    return p;
-}
-
-__device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
-
-// Exact 64-lane sum of int32 partials, returned as int64 (all lanes get the total).
-__device__ __forceinline__ long long wave_sum(int v)
-{
-    int lo = v & 0xffff;  // 0..65535
-    int hi = v >> 16;     // signed
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        lo += __shfl_xor(lo, o);
-        hi += __shfl_xor(hi, o);
-    }
-    return ((long long)hi << 16) + (long long)lo;
-}
-
-struct Weights {
-    int w00, w01, w10, w11;
-};
-
-__device__ __forceinline__ Weights bilinear_weights(float a, float b)
-{
-    Weights w;
-    w.w00 = (int)rintf((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
-    w.w01 = (int)rintf(a * (1.f - b) * (float)(1 << W_BITS));
-    w.w10 = (int)rintf((1.f - a) * b * (float)(1 << W_BITS));
-    w.w11 = (1 << W_BITS) - w.w00 - w.w01 - w.w10;
-    return w;
-}
-
-struct TrackResult {
-    float x, y;
-    float err;
-    int status;
-};
+using namespace lk;
 
 // LDS layout of one wave (offsets in bytes from the dynamic LDS base):
 //   [0, tile_bytes)            : u8 tile -- first the (w+3)x(h+3) source patch of I, later the
@@ -218,9 +179,9 @@ __device__ __forceinline__ TrackResult track_point(const Pyramid& PI, const Pyra
                 a22 += iyv * iyv;
             }
         }
-        const float A11 = (float)wave_sum(a11) * FLT_SCALE;
-        const float A12 = (float)wave_sum(a12) * FLT_SCALE;
-        const float A22 = (float)wave_sum(a22) * FLT_SCALE;
+        const float A11 = (float)wave_sum_exact(a11) * FLT_SCALE;
+        const float A12 = (float)wave_sum_exact(a12) * FLT_SCALE;
+        const float A22 = (float)wave_sum_exact(a22) * FLT_SCALE;
         float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
         const float dif = __fsub_rn(A11, A22);
         const float rad = __fadd_rn(__fmul_rn(dif, dif), __fmul_rn(__fmul_rn(4.f, A12), A12));
@@ -264,8 +225,8 @@ __device__ __forceinline__ TrackResult track_point(const Pyramid& PI, const Pyra
                     b2 += diff * ((int)dIval[k] >> 16);
                 }
             }
-            const float fb1 = (float)wave_sum(b1) * FLT_SCALE;
-            const float fb2 = (float)wave_sum(b2) * FLT_SCALE;
+            const float fb1 = (float)wave_sum_exact(b1) * FLT_SCALE;
+            const float fb2 = (float)wave_sum_exact(b2) * FLT_SCALE;
             const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
             const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
             nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
@@ -307,7 +268,7 @@ __device__ __forceinline__ TrackResult track_point(const Pyramid& PI, const Pyra
                     es += diff < 0 ? -diff : diff;
                 }
             }
-            const float errval = (float)wave_sum(es);
+            const float errval = (float)wave_sum_exact(es);
             R.err = __fdiv_rn(__fmul_rn(errval, 1.f), (float)(32 * win_w * win_h));
         }
     }
@@ -369,6 +330,7 @@ int launch_lk(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers
               bool fb)
 {
     if (n <= 0) return ICELK_OK;
+    if (!(P.flags & ICELK_FLAG_GENERIC_KERNEL) && launch_lk_fast(s, I, J, B, n, P, fb)) return ICELK_OK;
     const int npx = P.win_w * P.win_h;
     const int ppl = (npx + 63) / 64;
     const size_t lds = lk_lds_bytes(P);

@@ -1,0 +1,406 @@
+// k_lk_fast.hip -- window-size-specialised pyramidal Lucas-Kanade for gfx950 (21x21, 31x31, 35x35, ...).
+//
+// Same arithmetic, bit for bit, as the generic kernel in k_lk.hip (which stays the path for every other
+// winSize); this file is the MI355X-tuned form for the window sizes that BASELINE.json and the reference
+// (s1_lucaskanade_tracking.py:246, winSize=(35,35)) use.  One wavefront per feature, all levels and both
+// directions of the forward-backward check in one launch.
+//
+// What the compile-time window buys:
+//   * lane = one ROW SEGMENT of the window (S <= 8 contiguous pixels of one window row): 21x21 -> 63
+//     segments of 7 px, one per lane.  A lane reads its pixels from LDS as aligned dwords and realigns
+//     them with v_alignbyte, 6 ds_read_b32 per iteration instead of 28 ds_read_u8.
+//   * the Scharr derivative of the template is formed in registers, separably, from the 4 source rows a
+//     segment touches; nothing but the u8 source patch and the u8 search tile ever sits in LDS.
+//   * tiles are staged as aligned dwords, all global loads of a level (template patch AND search tile)
+//     issued before the first one is waited for; divisions by the tile pitch are by constants.
+//   * the five sums are exact integers reduced through the DPP network (lk_common.h), no LDS round trips.
+#include "lk_common.h"
+
+namespace icelk {
+
+namespace {
+
+using namespace lk;
+
+constexpr int kMargin = 6;  // search-tile margin R: the estimate may move +-R px before a restage
+
+constexpr int pick_seg(int ww, int wh)
+{
+    int best = 8, best_cost = 1 << 30;
+    for (int s = 5; s <= 8; s++) {
+        const int nseg = (ww + s - 1) / s;
+        const int tpl = (nseg * wh + 63) / 64;
+        const int cost = tpl * (s + 3);
+        if (cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
+template <int WW, int WH>
+struct Cfg {
+    static constexpr int S = pick_seg(WW, WH);       // pixels per row segment
+    static constexpr int NSEG = (WW + S - 1) / S;    // segments per window row
+    static constexpr int NTASK = NSEG * WH;
+    static constexpr int TPL = (NTASK + 63) / 64;    // segments per lane
+    static constexpr int ITW = WW + 3, ITH = WH + 3;  // template source patch (1-px ring for Scharr + bilinear)
+    static constexpr int IPD = (ITW + 2) / 4 + 1;     // LDS row pitch in dwords (any 4-byte phase)
+    static constexpr int JTW = WW + 1 + 2 * kMargin, JTH = WH + 1 + 2 * kMargin;
+    static constexpr int JPD = (JTW + 2) / 4 + 1;
+    static constexpr int I_DW = IPD * ITH, J_DW = JPD * JTH;
+    static constexpr int LDS_DW = I_DW + J_DW + 8;    // +8: realignment reads may run 3 dwords past a row
+};
+
+// ---- tile staging ---------------------------------------------------------------------------------
+// A tile whose top-left image pixel is (x0, y0) is kept in LDS as the aligned dwords that cover each of
+// its rows: LDS byte (r*PD*4 + (x0 & 3) + tx) holds image pixel (x0 + tx, y0 + r).
+template <int PD, int TH>
+struct TileRegs {
+    static constexpr int N = (PD * TH + 63) / 64;
+    uint32_t v[N];
+};
+
+template <int PD, int TH>
+__device__ __forceinline__ void tile_issue(TileRegs<PD, TH>& t, const Level& L, int x0, int y0, int lane)
+{
+    const uint8_t* base = L.ptr + (size_t)y0 * L.pitch + (x0 & ~3);
+#pragma unroll
+    for (int m = 0; m < TileRegs<PD, TH>::N; m++) {
+        const int i = lane + 64 * m;
+        const int r = i / PD, c = i - r * PD;
+        t.v[m] = 0;
+        if (i < PD * TH) t.v[m] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * L.pitch + 4 * c);
+    }
+}
+
+template <int PD, int TH>
+__device__ __forceinline__ void tile_commit(const TileRegs<PD, TH>& t, uint32_t* lds, int lane)
+{
+#pragma unroll
+    for (int m = 0; m < TileRegs<PD, TH>::N; m++) {
+        const int i = lane + 64 * m;
+        if (i < PD * TH) lds[i] = t.v[m];
+    }
+}
+
+// border tiles: byte-wise with reflect-101 (only features within a window of the image edge)
+template <int PD, int TW, int TH>
+__device__ __forceinline__ void tile_border(uint32_t* lds, const Level& L, int x0, int y0, int lane)
+{
+    uint8_t* b = reinterpret_cast<uint8_t*>(lds);
+    const int cs = x0 & 3;
+    for (int i = lane; i < TW * TH; i += 64) {
+        const int ty = i / TW, tx = i - ty * TW;
+        b[ty * PD * 4 + cs + tx] = L.ptr[(size_t)reflect101(y0 + ty, L.h) * L.pitch + reflect101(x0 + tx, L.w)];
+    }
+}
+
+__device__ __forceinline__ bool tile_inside(const Level& L, int x0, int y0, int tw, int th)
+{
+    return x0 >= 0 && y0 >= 0 && x0 + tw <= L.w && y0 + th <= L.h;
+}
+
+// NB bytes starting at byte offset `off` of an LDS row, as ints
+template <int NB>
+__device__ __forceinline__ void row_bytes(const uint32_t* row, int off, int (&out)[NB])
+{
+    constexpr int ND = (NB + 3 + 3) / 4;  // dwords that can be touched
+    const uint32_t* p = row + (off >> 2);
+    const int sh = off & 3;
+    uint32_t d[ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++) d[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < (NB + 3) / 4; i++) {
+        const uint32_t a = __builtin_amdgcn_alignbyte(d[i + 1 < ND ? i + 1 : i], d[i], sh);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (4 * i + k < NB) out[4 * i + k] = (int)((a >> (8 * k)) & 255u);
+    }
+}
+
+template <int WW, int WH>
+__device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const Pyramid& PJ, float p0x, float p0y,
+                                                        const LKParams& P, uint32_t* ldsI, uint32_t* ldsJ, int lane)
+{
+    using C = Cfg<WW, WH>;
+    constexpr int S = C::S;
+    constexpr int R = kMargin;
+    const float half_x = (WW - 1) * 0.5f, half_y = (WH - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+
+    // this lane's row segments
+    int trow[C::TPL], tcol[C::TPL], tlen[C::TPL];
+#pragma unroll
+    for (int k = 0; k < C::TPL; k++) {
+        const int t = lane + 64 * k;
+        const bool used = t < C::NTASK;   // surplus lanes work on segment 0 with every pixel masked off
+        const int row = used ? t / C::NSEG : 0;
+        trow[k] = row;
+        tcol[k] = used ? (t - row * C::NSEG) * S : 0;
+        tlen[k] = used ? (WW - tcol[k] < S ? WW - tcol[k] : S) : 0;
+    }
+
+    TrackResult Rz;
+    Rz.status = 1;
+    Rz.err = 0.f;
+    float sx = 0.f, sy = 0.f;  // the stored nextPts value
+
+    for (int level = P.top_level; level >= 0; level--) {
+        const Level LI = PI.lv[level];
+        const Level LJ = PJ.lv[level];
+        const float scale = 1.f / (float)(1 << level);
+        float px = p0x * scale, py = p0y * scale;
+        if (level == P.top_level) { sx = px; sy = py; }
+        else { sx = sx * 2.f; sy = sy * 2.f; }
+        px -= half_x; py -= half_y;
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        if (ipx < -WW || ipx >= LI.w || ipy < -WH || ipy >= LI.h) {
+            if (level == 0) { Rz.status = 0; Rz.err = 0.f; }
+            continue;
+        }
+        const Weights wi = bilinear_weights(px - (float)ipx, py - (float)ipy);
+
+        // ---- stage the template source patch and (speculatively) the first search tile ---------------
+        float nx = sx - half_x, ny = sy - half_y;
+        int jx0 = 0, jy0 = 0;
+        bool staged = false;
+        const int ix0 = ipx - 1, iy0 = ipy - 1;
+        const bool i_inside = tile_inside(LI, ix0, iy0, C::ITW, C::ITH);
+        {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            const bool j_ok = !(inx < -WW || inx >= LJ.w || iny < -WH || iny >= LJ.h);
+            const int tjx = inx - R, tjy = iny - R;
+            const bool j_inside = j_ok && tile_inside(LJ, tjx, tjy, C::JTW, C::JTH);
+            __syncthreads();
+            TileRegs<C::IPD, C::ITH> ti;
+            TileRegs<C::JPD, C::JTH> tj;
+            if (i_inside) tile_issue(ti, LI, ix0, iy0, lane);
+            if (j_inside) tile_issue(tj, LJ, tjx, tjy, lane);
+            if (i_inside) tile_commit(ti, ldsI, lane);
+            else tile_border<C::IPD, C::ITW, C::ITH>(ldsI, LI, ix0, iy0, lane);
+            if (j_inside) tile_commit(tj, ldsJ, lane);
+            else if (j_ok) tile_border<C::JPD, C::JTW, C::JTH>(ldsJ, LJ, tjx, tjy, lane);
+            if (j_ok) { jx0 = tjx; jy0 = tjy; staged = true; }
+            __syncthreads();
+        }
+
+        // ---- template patch into registers: I (x32), Ix, Iy ------------------------------------------
+        int Iv[C::TPL][S], Ixv[C::TPL][S], Iyv[C::TPL][S];
+        int a11 = 0, a12 = 0, a22 = 0;
+        const int ics = ix0 & 3;
+#pragma unroll
+        for (int k = 0; k < C::TPL; k++) {
+            int Bv[4][S + 3];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                row_bytes<S + 3>(ldsI + (trow[k] + r) * C::IPD, ics + tcol[k], Bv[r]);
+            int dxv[2][S + 1], dyv[2][S + 1];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                int t0[S + 3], t1[S + 3];
+#pragma unroll
+                for (int j = 0; j < S + 3; j++) {
+                    t0[j] = (Bv[r][j] + Bv[r + 2][j]) * 3 + Bv[r + 1][j] * 10;
+                    t1[j] = Bv[r + 2][j] - Bv[r][j];
+                }
+#pragma unroll
+                for (int i = 0; i < S + 1; i++) {
+                    dxv[r][i] = t0[i + 2] - t0[i];
+                    dyv[r][i] = (t1[i + 2] + t1[i]) * 3 + t1[i + 1] * 10;
+                }
+                if (!i_inside) {
+                    // derivative image is zero outside the frame (BORDER_CONSTANT), SURVEY.md A.4
+                    const int gy = ipy + trow[k] + r;
+#pragma unroll
+                    for (int i = 0; i < S + 1; i++) {
+                        const int gx = ipx + tcol[k] + i;
+                        if (gx < 0 || gx >= LI.w || gy < 0 || gy >= LI.h) { dxv[r][i] = 0; dyv[r][i] = 0; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < S; j++) {
+                const bool on = j < tlen[k];
+                const int iv = descale(Bv[1][j + 1] * wi.w00 + Bv[1][j + 2] * wi.w01 + Bv[2][j + 1] * wi.w10 +
+                                       Bv[2][j + 2] * wi.w11, W_BITS - 5);
+                const int ixv = descale(dxv[0][j] * wi.w00 + dxv[0][j + 1] * wi.w01 + dxv[1][j] * wi.w10 +
+                                        dxv[1][j + 1] * wi.w11, W_BITS);
+                const int iyv = descale(dyv[0][j] * wi.w00 + dyv[0][j + 1] * wi.w01 + dyv[1][j] * wi.w10 +
+                                        dyv[1][j + 1] * wi.w11, W_BITS);
+                Iv[k][j] = on ? iv : 0;
+                Ixv[k][j] = on ? ixv : 0;
+                Iyv[k][j] = on ? iyv : 0;
+                a11 += Ixv[k][j] * Ixv[k][j];
+                a12 += Ixv[k][j] * Iyv[k][j];
+                a22 += Iyv[k][j] * Iyv[k][j];
+            }
+        }
+        const float A11 = (float)wave_sum_exact(a11) * FLT_SCALE;
+        const float A12 = (float)wave_sum_exact(a12) * FLT_SCALE;
+        const float A22 = (float)wave_sum_exact(a22) * FLT_SCALE;
+        float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
+        const float dif = __fsub_rn(A11, A22);
+        const float rad = __fadd_rn(__fmul_rn(dif, dif), __fmul_rn(__fmul_rn(4.f, A12), A12));
+        const float minEig = __fdiv_rn(__fsub_rn(__fadd_rn(A22, A11), sqrtf(rad)), (float)(2 * WW * WH));
+        if (P.flags & ICELK_FLAG_MIN_EIGENVALS) Rz.err = minEig;
+        if (minEig < P.min_eig_thr || D < 1.1920928955078125e-07f) {
+            if (level == 0) Rz.status = 0;
+            continue;
+        }
+        D = __fdiv_rn(1.f, D);
+
+        // ---- iterations ---------------------------------------------------------------------------
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < P.max_count; j++) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -WW || inx >= LJ.w || iny < -WH || iny >= LJ.h) {
+                if (level == 0) Rz.status = 0;
+                break;
+            }
+            if (!staged || inx < jx0 || inx > jx0 + 2 * R || iny < jy0 || iny > jy0 + 2 * R) {
+                jx0 = inx - R; jy0 = iny - R;
+                __syncthreads();
+                if (tile_inside(LJ, jx0, jy0, C::JTW, C::JTH)) {
+                    TileRegs<C::JPD, C::JTH> tj;
+                    tile_issue(tj, LJ, jx0, jy0, lane);
+                    tile_commit(tj, ldsJ, lane);
+                } else {
+                    tile_border<C::JPD, C::JTW, C::JTH>(ldsJ, LJ, jx0, jy0, lane);
+                }
+                __syncthreads();
+                staged = true;
+            }
+            const Weights wj = bilinear_weights(nx - (float)inx, ny - (float)iny);
+            const int joff = (jx0 & 3) + (inx - jx0);
+            const uint32_t* jrow0 = ldsJ + (iny - jy0) * C::JPD;
+            int b1 = 0, b2 = 0;
+#pragma unroll
+            for (int k = 0; k < C::TPL; k++) {
+                int J0[S + 1], J1[S + 1];
+                row_bytes<S + 1>(jrow0 + trow[k] * C::JPD, joff + tcol[k], J0);
+                row_bytes<S + 1>(jrow0 + (trow[k] + 1) * C::JPD, joff + tcol[k], J1);
+#pragma unroll
+                for (int q = 0; q < S; q++) {
+                    const int diff = descale(J0[q] * wj.w00 + J0[q + 1] * wj.w01 + J1[q] * wj.w10 + J1[q + 1] * wj.w11,
+                                             W_BITS - 5) - Iv[k][q];
+                    b1 += diff * Ixv[k][q];
+                    b2 += diff * Iyv[k][q];
+                }
+            }
+            const float fb1 = (float)wave_sum_exact(b1) * FLT_SCALE;
+            const float fb2 = (float)wave_sum_exact(b2) * FLT_SCALE;
+            const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
+            const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
+            nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
+            sx = __fadd_rn(nx, half_x); sy = __fadd_rn(ny, half_y);
+            if (__dadd_rn(__dmul_rn((double)dx, (double)dx), __dmul_rn((double)dy, (double)dy)) <= P.eps2) break;
+            if (j > 0 && fabs((double)__fadd_rn(dx, pdx)) < 0.01 && fabs((double)__fadd_rn(dy, pdy)) < 0.01) {
+                sx = __fsub_rn(sx, __fmul_rn(dx, 0.5f));
+                sy = __fsub_rn(sy, __fmul_rn(dy, 0.5f));
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+
+        // ---- residual error at level 0 ----------------------------------------------------------------
+        if (Rz.status && level == 0 && !(P.flags & ICELK_FLAG_MIN_EIGENVALS)) {
+            const float qx = sx - half_x, qy = sy - half_y;
+            const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
+            if (iqx < -WW || iqx >= LJ.w || iqy < -WH || iqy >= LJ.h) {
+                Rz.status = 0;
+                continue;
+            }
+            if (!staged || iqx < jx0 || iqx > jx0 + 2 * R || iqy < jy0 || iqy > jy0 + 2 * R) {
+                jx0 = iqx - R; jy0 = iqy - R;
+                __syncthreads();
+                if (tile_inside(LJ, jx0, jy0, C::JTW, C::JTH)) {
+                    TileRegs<C::JPD, C::JTH> tj;
+                    tile_issue(tj, LJ, jx0, jy0, lane);
+                    tile_commit(tj, ldsJ, lane);
+                } else {
+                    tile_border<C::JPD, C::JTW, C::JTH>(ldsJ, LJ, jx0, jy0, lane);
+                }
+                __syncthreads();
+                staged = true;
+            }
+            const Weights we = bilinear_weights(qx - (float)iqx, qy - (float)iqy);
+            const int joff = (jx0 & 3) + (iqx - jx0);
+            const uint32_t* jrow0 = ldsJ + (iqy - jy0) * C::JPD;
+            int es = 0;
+#pragma unroll
+            for (int k = 0; k < C::TPL; k++) {
+                int J0[S + 1], J1[S + 1];
+                row_bytes<S + 1>(jrow0 + trow[k] * C::JPD, joff + tcol[k], J0);
+                row_bytes<S + 1>(jrow0 + (trow[k] + 1) * C::JPD, joff + tcol[k], J1);
+#pragma unroll
+                for (int q = 0; q < S; q++) {
+                    const int diff = descale(J0[q] * we.w00 + J0[q + 1] * we.w01 + J1[q] * we.w10 + J1[q + 1] * we.w11,
+                                             W_BITS - 5) - Iv[k][q];
+                    es += q < tlen[k] ? (diff < 0 ? -diff : diff) : 0;
+                }
+            }
+            const float errval = (float)wave_sum_exact(es);
+            Rz.err = __fdiv_rn(__fmul_rn(errval, 1.f), (float)(32 * WW * WH));
+        }
+    }
+    Rz.x = sx;
+    Rz.y = sy;
+    return Rz;
+}
+
+template <int WW, int WH, bool FB>
+__global__ __launch_bounds__(64) void k_lk_fast(Pyramid PI, Pyramid PJ, LKBuffers B, int n, LKParams P)
+{
+    using C = Cfg<WW, WH>;
+    __shared__ uint32_t lds[C::LDS_DW];
+    const int f = blockIdx.x;
+    const int count = B.n_dev ? *B.n_dev : n;
+    if (f >= count) return;
+    const int lane = threadIdx.x;
+    uint32_t* ldsI = lds;
+    uint32_t* ldsJ = lds + C::I_DW;
+    const float p0x = B.p_in[2 * f], p0y = B.p_in[2 * f + 1];
+    const TrackResult r1 = track_point_fast<WW, WH>(PI, PJ, p0x, p0y, P, ldsI, ldsJ, lane);
+    if (lane == 0) {
+        if (B.p_fwd) { B.p_fwd[2 * f] = r1.x; B.p_fwd[2 * f + 1] = r1.y; }
+        if (B.st_fwd) B.st_fwd[f] = (uint8_t)r1.status;
+        if (B.err_fwd) B.err_fwd[f] = r1.err;
+    }
+    if (FB) {
+        const TrackResult r2 = track_point_fast<WW, WH>(PJ, PI, r1.x, r1.y, P, ldsI, ldsJ, lane);
+        if (lane == 0) {
+            if (B.p_bwd) { B.p_bwd[2 * f] = r2.x; B.p_bwd[2 * f + 1] = r2.y; }
+            if (B.st_bwd) B.st_bwd[f] = (uint8_t)r2.status;
+            if (B.err_bwd) B.err_bwd[f] = r2.err;
+            const float ddx = fabsf(__fsub_rn(p0x, r2.x)), ddy = fabsf(__fsub_rn(p0y, r2.y));
+            const float d = sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
+            if (B.dist) B.dist[f] = d;
+            if (B.valid) B.valid[f] = d < P.fb_thr ? 1 : 0;
+        }
+    }
+}
+
+template <int WW, int WH>
+void launch_fast(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
+                 bool fb)
+{
+    if (fb) hipLaunchKernelGGL((k_lk_fast<WW, WH, true>), dim3(n), dim3(64), 0, s, I, J, B, n, P);
+    else hipLaunchKernelGGL((k_lk_fast<WW, WH, false>), dim3(n), dim3(64), 0, s, I, J, B, n, P);
+}
+
+}  // namespace
+
+// Returns true when a specialised kernel exists for this window (and INITIAL_FLOW is not requested).
+bool launch_lk_fast(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
+                    bool fb)
+{
+    if (P.flags & ICELK_FLAG_INITIAL_FLOW) return false;
+    if (P.win_w == 21 && P.win_h == 21) launch_fast<21, 21>(s, I, J, B, n, P, fb);
+    else if (P.win_w == 31 && P.win_h == 31) launch_fast<31, 31>(s, I, J, B, n, P, fb);
+    else if (P.win_w == 35 && P.win_h == 35) launch_fast<35, 35>(s, I, J, B, n, P, fb);
+    else if (P.win_w == 15 && P.win_h == 15) launch_fast<15, 15>(s, I, J, B, n, P, fb);
+    else return false;
+    return true;
+}
+
+}  // namespace icelk

@@ -1,0 +1,65 @@
+// lk_common.h -- device helpers shared by the generic (k_lk.hip) and the specialised (k_lk_fast.hip)
+// Lucas-Kanade kernels.  Arithmetic follows SURVEY.md A.6 (OpenCV LKTrackerInvoker, restated).
+#pragma once
+#include "icelk_internal.h"
+
+namespace icelk {
+namespace lk {
+
+constexpr int W_BITS = 14;
+
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+__device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
+
+struct Weights {
+    int w00, w01, w10, w11;
+};
+
+// iw = cvRound(frac products * 2^14); cvRound = round-half-even (v_rndne_f32)
+__device__ __forceinline__ Weights bilinear_weights(float a, float b)
+{
+    Weights w;
+    w.w00 = (int)rintf((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
+    w.w01 = (int)rintf(a * (1.f - b) * (float)(1 << W_BITS));
+    w.w10 = (int)rintf((1.f - a) * b * (float)(1 << W_BITS));
+    w.w11 = (1 << W_BITS) - w.w00 - w.w01 - w.w10;
+    return w;
+}
+
+struct TrackResult {
+    float x, y;
+    float err;
+    int status;
+};
+
+// 64-lane integer sum through the DPP network (no LDS traffic): row prefix sums with row_shr 1/2/4/8,
+// then row_bcast15 / row_bcast31 carry the row totals up; lane 63 ends with the wave total, which is
+// read back as a scalar.
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);  // row_bcast15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);  // row_bcast31 -> rows 2,3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Exact sum of per-lane int32 partials as int64: the partial is split into a 16-bit low part and a
+// signed high part so that neither 64-lane sum can overflow 32 bits.
+__device__ __forceinline__ long long wave_sum_exact(int v)
+{
+    const int lo = wave_sum_i32(v & 0xffff);
+    const int hi = wave_sum_i32(v >> 16);
+    return ((long long)hi << 16) + (long long)lo;
+}
+
+}  // namespace lk
+}  // namespace icelk

@@ -41,6 +41,8 @@ typedef struct icelk_ctx icelk_t;
 /* cv2.OPTFLOW_USE_INITIAL_FLOW / cv2.OPTFLOW_LK_GET_MIN_EIGENVALS */
 #define ICELK_FLAG_INITIAL_FLOW 4
 #define ICELK_FLAG_MIN_EIGENVALS 8
+/* testing aid: force the window-size-generic LK kernel where a specialised one exists (same results) */
+#define ICELK_FLAG_GENERIC_KERNEL 0x100
 /* fixed-point coefficient sets of cv2.cvtColor(COLOR_BGR2GRAY): OpenCV 3.x (14 bit), 4.x (15 bit) */
 #define ICELK_GRAY_CV3 3
 #define ICELK_GRAY_CV4 4

@@ -173,3 +173,35 @@ def test_good_features_mask_and_none(ctx, orc, synth):
     ctx.upload_gray(0, img)
     assert ctx.good_features(0, 100, 0.01, 10, True, 3) is None
     ctx.set_mask(None)
+
+
+@pytest.mark.parametrize("win,maxlevel", [((21, 21), 3), ((31, 31), 5), ((35, 35), 4), ((15, 15), 2)])
+def test_specialised_equals_generic_kernel(ctx, orc, synth, win, maxlevel):
+    """k_lk_fast (compile-time window) and k_lk (generic) must agree bit for bit, borders included."""
+    w, h = 640, 480
+    img0, img1 = _pair(synth, w, h, -700, 555)
+    rng = np.random.RandomState(win[0])
+    pts = _points(rng, 1500, w, h, border=-20.0)
+    ctx.upload_gray(0, img0)
+    ctx.upload_gray(1, img1)
+    a = ctx.pyrlk(0, 1, pts, None, win, maxlevel, CRIT_DEFAULT, 0)
+    b = ctx.pyrlk(0, 1, pts, None, win, maxlevel, CRIT_DEFAULT, 0x100)
+    q = orc.pyrlk(img0, img1, pts, None, win, maxlevel, CRIT_DEFAULT)
+    for x, y, z in zip(a, b, q):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+        assert np.array_equal(x.view(np.uint8), z.view(np.uint8))
+
+
+def test_large_motion_restage(ctx, orc, synth):
+    """A shift beyond the staged search margin forces the tile restage path."""
+    w, h = 640, 480
+    img0, img1 = _pair(synth, w, h, 256 * 9, -256 * 7)
+    rng = np.random.RandomState(3)
+    pts = _points(rng, 800, w, h, border=30.0)
+    ctx.upload_gray(0, img0)
+    ctx.upload_gray(1, img1)
+    for win, ml in (((21, 21), 0), ((21, 21), 1), ((35, 35), 1)):
+        a = ctx.pyrlk(0, 1, pts, None, win, ml, (3, 30, 0.01))
+        q = orc.pyrlk(img0, img1, pts, None, win, ml, (3, 30, 0.01))
+        for x, z in zip(a, q):
+            assert np.array_equal(x.view(np.uint8), z.view(np.uint8))
