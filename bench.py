@@ -233,10 +233,10 @@ def main():
             kern["pyramid"] = {"bound": "hbm", "algorithmic_bytes_per_frame": alg, "us_per_frame": per_frame_us,
                                "achieved_GBps": alg / (per_frame_us * 1e-6) / 1e9,
                                "frac": alg / (per_frame_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
-        eg = prof.get("min_eig")
+        eg = prof.get("corner_candidates")
         if eg:
-            alg = 5.0 * w * h   # 1 B/px in, 4 B/px eigenvalue map out
-            kern["min_eig"] = {"bound": "hbm", "algorithmic_bytes_per_launch": alg, "avg_launch_us": eg["avg_us"],
+            alg = 1.0 * w * h   # 1 B/px in; the eigenvalue map is never materialised (k_corners.hip)
+            kern["corner_candidates"] = {"bound": "hbm", "algorithmic_bytes_per_launch": alg, "avg_launch_us": eg["avg_us"],
                                "achieved_GBps": alg / (eg["avg_us"] * 1e-6) / 1e9,
                                "frac": alg / (eg["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
         out["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2)} for k, v in prof.items()}

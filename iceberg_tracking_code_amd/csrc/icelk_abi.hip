@@ -1,6 +1,7 @@
 // icelk_abi.hip -- handle, device memory and the extern "C" entry points declared in include/icelk.h.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -13,7 +14,8 @@ namespace icelk {
 constexpr int kMaxVert = 17;  // vertices per track kept on the device (track_len <= 16; reference uses 2)
 
 static const char* kKernelNames[K_COUNT_] = {
-    "bgr2gray", "pyrdown", "lk", "lk_fb", "min_eig", "nms_collect", "cells", "suppress", "emit", "compact", "synth",
+    "bgr2gray", "pyrdown", "lk", "lk_fb", "corner_candidates", "unused5", "unused6", "min_distance", "sort_emit",
+    "compact", "synth",
 };
 
 struct Ctx {
@@ -269,7 +271,7 @@ static void destroy_ctx(Ctx* c)
     void* ptrs[] = {c->d_bgr, c->d_mask, c->d_p0, c->d_p1, c->d_p0r, c->d_err_f, c->d_err_b, c->d_dist, c->d_corners,
                     c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.max_key, c->D.cand, c->D.cand_count,
                     c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.cell_cand, c->D.state, c->D.undecided,
-                    c->D.acc, c->D.acc_sorted, c->D.acc_count, c->D.sort_tmp, c->d_live[0], c->d_live[1],
+                    c->D.acc, c->D.acc_sorted, c->D.acc_count, c->D.blk_count, c->D.sort_tmp, c->d_live[0], c->d_live[1],
                     c->d_origin[0], c->d_origin[1], c->d_nlive, c->d_tracked, c->d_tracks, c->d_quality,
                     c->d_out_tracks, c->d_out_quality};
     for (void* p : ptrs)
@@ -300,46 +302,53 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
     }
     DetectScratch& D = c->D;
     *n_out = 0;
-    HIPCHK(c, hipMemsetAsync(D.max_key, 0, sizeof(unsigned), c->stream));
-    HIPCHK(c, hipMemsetAsync(D.cand_count, 0, sizeof(int), c->stream));
+    const bool generic = getenv("ICELK_GENERIC_CORNERS") != nullptr;
     {
         ProfScope p(c, K_EIG);
-        launch_min_eig(c->stream, s.lv[0], block_size, D.eig, mask, c->mask_pitch, D.max_key);
+        launch_candidates(c->stream, D, s.lv[0], block_size, mask, c->mask_pitch, quality, generic, nullptr);
     }
-    rc = check_launch(c, "min_eig");
+    rc = check_launch(c, "corner candidates");
     if (rc) return rc;
-    {
-        ProfScope p(c, K_NMS);
-        launch_nms_collect(c->stream, D.eig, w, h, mask, c->mask_pitch, D.max_key, quality, D.cand, D.cand_count,
-                           D.cand_cap);
-    }
-    rc = check_launch(c, "nms_collect");
-    if (rc) return rc;
-    int n_cand = 0;
-    HIPCHK(c, hipMemcpyAsync(&n_cand, D.cand_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (n_cand == 0) return ICELK_OK;
-    if (n_cand > D.cand_cap) FAIL(c, ICELK_ECAP, "corner candidate buffer overflow");
-
+    // one host round trip per detection: {candidates, accepted, undecided}
+    int counts[3] = {0, 0, 0};
+    const int* cand_count_ptr = D.cand_count;
+    auto fetch = [&]() -> int {
+        HIPCHK(c, hipMemcpyAsync(&counts[0], cand_count_ptr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&counts[1], D.acc_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&counts[2], D.undecided + suppress_launch_count() - 1, sizeof(int),
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return ICELK_OK;
+    };
     const unsigned long long* sorted = nullptr;
     int total = 0;
     if (min_distance >= 1) {
         const int cell = (int)lrint(min_distance);
         const size_t ncell = (size_t)((w + cell - 1) / cell) * ((h + cell - 1) / cell);
         if (ncell + 1 > c->ncell_cap) FAIL(c, ICELK_ECAP, "cell grid larger than allocated");
+        cand_count_ptr = D.cell_start + ncell;
         {
             ProfScope p(c, K_SUPPRESS);
-            rc = run_min_distance(c->stream, D, w, h, n_cand, min_distance, c->err);
+            launch_min_distance(c->stream, D, w, h, min_distance, quality);
         }
-        if (rc) return rc;
         rc = check_launch(c, "min_distance");
         if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(&total, D.acc_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((rc = fetch())) return rc;
+        for (int guard = 0; counts[2] != 0; guard++) {
+            if (guard > 100000) FAIL(c, ICELK_EHIP, "min-distance suppression did not converge");
+            continue_min_distance(c->stream, D, w, h, min_distance);
+            if ((rc = fetch())) return rc;
+        }
+        total = counts[1];
+        if (total == 0) return ICELK_OK;
         sort_keys_desc(c->stream, D, D.acc, D.acc_sorted, total);
         sorted = D.acc_sorted;
     } else {
-        total = n_cand;
+        launch_flatten(c->stream, D, quality);
+        HIPCHK(c, hipMemsetAsync(D.undecided, 0, sizeof(int) * 8, c->stream));
+        if ((rc = fetch())) return rc;
+        total = counts[0];
+        if (total == 0) return ICELK_OK;
         sort_keys_desc(c->stream, D, D.cand, D.cell_cand, total);
         sorted = D.cell_cand;
     }
@@ -481,7 +490,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
     c->mask_pitch = align_up(max_w, kPitchAlign);
     const size_t np = (size_t)max_pts;
     DetectScratch& D = c->D;
-    D.cand_cap = (int)std::min<size_t>(npx, (size_t)1 << 30);
+    D.cand_cap = (int)std::min<size_t>(candidate_capacity(max_w, max_h), (size_t)1 << 30);
     c->ncell_cap = npx + 1;
     D.sort_tmp_bytes = sort_tmp_bytes(D.cand_cap);
     if ((rc = dmalloc(c, &c->d_bgr, (size_t)c->bgr_pitch * max_h)) || (rc = dmalloc(c, &c->d_mask, (size_t)c->mask_pitch * max_h)) ||
@@ -494,7 +503,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &D.cell_fill, c->ncell_cap)) || (rc = dmalloc(c, &D.cell_cand, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.state, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.undecided, 64)) ||
         (rc = dmalloc(c, &D.acc, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.acc_sorted, (size_t)D.cand_cap)) ||
-        (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, (uint8_t**)&D.sort_tmp, D.sort_tmp_bytes)) ||
+        (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, &D.blk_count, candidate_blocks(max_w, max_h) * 4)) || (rc = dmalloc(c, (uint8_t**)&D.sort_tmp, D.sort_tmp_bytes)) ||
         (rc = dmalloc(c, &c->d_live[0], 2 * np)) || (rc = dmalloc(c, &c->d_live[1], 2 * np)) ||
         (rc = dmalloc(c, &c->d_origin[0], np)) || (rc = dmalloc(c, &c->d_origin[1], np)) || (rc = dmalloc(c, &c->d_nlive, 2)) ||
         (rc = dmalloc(c, &c->d_tracked, 1)) || (rc = dmalloc(c, &c->d_tracks, np * kMaxVert * 2)) ||
@@ -844,10 +853,14 @@ int icelk_min_eig_map(icelk_t* h, int slot, int block_size, float* host_out, int
     if (min_eig_lds_bytes(block_size) > 150 * 1024) FAIL(c, ICELK_EARG, "blockSize too large");
     rc = wait_slot(c, slot);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->D.max_key, 0, sizeof(unsigned), c->stream));
     {
         ProfScope p(c, K_EIG);
-        launch_min_eig(c->stream, s.lv[0], block_size, c->D.eig, nullptr, 0, c->D.max_key);
+        if (fused_block_size(block_size) && !getenv("ICELK_GENERIC_CORNERS")) {
+            launch_candidates(c->stream, c->D, s.lv[0], block_size, nullptr, 0, 1.0, false, c->D.eig);
+        } else {
+            HIPCHK(c, hipMemsetAsync(c->D.max_key, 0, sizeof(unsigned), c->stream));
+            launch_min_eig(c->stream, s.lv[0], block_size, c->D.eig, nullptr, 0, c->D.max_key);
+        }
     }
     rc = check_launch(c, "min_eig");
     if (rc) return rc;

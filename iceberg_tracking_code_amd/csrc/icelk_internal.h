@@ -108,15 +108,25 @@ struct DetectScratch {
     int* acc_count;        // 1
     void* sort_tmp;
     size_t sort_tmp_bytes;
+    int* blk_count;        // candidates per producer workgroup (region layout, see k_corners.hip)
+    int src_nblk, src_region;   // geometry of the candidate regions of the detection in flight
 };
 void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig, const uint8_t* mask,
                     int mask_pitch, unsigned* max_key);
-void launch_nms_collect(hipStream_t s, const float* eig, int w, int h, const uint8_t* mask, int mask_pitch,
-                        const unsigned* max_key, double quality, unsigned long long* cand, int* cand_count,
-                        int cand_cap);
-// greedy min-distance suppression on the device; returns via acc/acc_count (unsorted)
-int run_min_distance(hipStream_t s, DetectScratch& D, int w, int h, int n_cand, double min_distance,
-                     std::string& err);
+bool fused_block_size(int bs);
+// K6+K7: local maxima into per-workgroup regions of D.acc_sorted (stream order, no host sync)
+void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
+                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null);
+size_t candidate_capacity(int w, int h);   // keys the region layout needs
+size_t candidate_blocks(int w, int h);
+// minDistance < 1: candidates above the threshold, flat in D.cand / D.cand_count
+void launch_flatten(hipStream_t s, DetectScratch& D, double quality);
+// K8: regions -> D.acc / D.acc_count (unsorted accepted keys); candidates counted in D.cell_start[ncell];
+// D.undecided[suppress_launch_count()-1] != 0 afterwards means the relaxation has not converged yet: call
+// continue_min_distance and look again.
+void launch_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double min_distance, double quality);
+void continue_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double min_distance);
+int suppress_launch_count();
 size_t sort_tmp_bytes(int n);
 void sort_keys_desc(hipStream_t s, DetectScratch& D, const unsigned long long* in, unsigned long long* out,
                     int n);

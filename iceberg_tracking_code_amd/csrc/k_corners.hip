@@ -1,23 +1,30 @@
 // k_corners.hip -- Shi-Tomasi corner detection for gfx950.
 //
 // Replaces cv2.goodFeaturesToTrack(frame_gray, mask=mask, **feature_params) at
-// s1_lucaskanade_tracking.py:437 (s0_1_test_lucaskanade_tracking.py:167).  Arithmetic restated
-// from OpenCV's cornerMinEigenVal / goodFeaturesToTrack (OpenCV is not part of
-// /root/reference).
+// s1_lucaskanade_tracking.py:437 (s0_1_test_lucaskanade_tracking.py:167).  Arithmetic restated from OpenCV's
+// cornerMinEigenVal / goodFeaturesToTrack (OpenCV is not part of /root/reference).
 //
 // Stages
-//   K6 k_min_eig      fused Sobel -> covariance products -> blockSize^2 box sum -> min eigenvalue,
-//                     one tile per workgroup through LDS, plus the masked maximum of the map
-//                     (order-preserving atomicMax) -- the f32 Dx, Dy and 3-channel covariance
-//                     images OpenCV materialises (5 x 4 B/px) never exist in HBM.
-//   K7 k_nms_collect  threshold (max * qualityLevel), 3x3 non-max test, mask, 1-px border;
-//                     survivors appended as 64-bit keys (response bits << 32 | raster index).
-//   K8 min distance   OpenCV accepts candidates greedily in response order.  Equivalent parallel
-//                     form: a candidate is accepted iff no ACCEPTED candidate of higher priority
-//                     lies closer than minDistance; iterate "reject if an accepted stronger
-//                     neighbour exists / accept if every stronger neighbour is rejected" to the
-//                     fixed point over a cell grid of round(minDistance) px (3x3 cell search, as
-//                     OpenCV's grid).  Only the accepted set is sorted.
+//   K6+K7 fused (k_eig_nms<BS>, blockSize 3/5/7/10): one tile per workgroup, everything through LDS:
+//         u8 tile -> Sobel -> covariance products -> blockSize^2 box sums (ordered double sums, register
+//         blocked) -> min eigenvalue (+1 px halo) -> 3x3 non-max test, mask, 1-px border -> local maxima
+//         appended as 64-bit keys (response key << 32 | raster index), plus the masked maximum of the map
+//         (order-preserving atomicMax).  Neither OpenCV's f32 Dx/Dy/covariance images (5 x 4 B/px) nor the
+//         eigenvalue map itself ever exist in HBM: 1 B/px is read, ~8 B per local maximum written.
+//         The quality threshold (max * qualityLevel) is applied to the candidate list afterwards
+//         (k_filter): for max > 0,  v > thr && v == dilate3x3(threshold_tozero(eig))  <=>  v > thr && v >= its
+//         8 raw neighbours; for max <= 0 OpenCV finds no corner either.
+//   K6, K7 separate (k_min_eig, k_nms_collect): any other blockSize, and the eigenvalue-map read-back.
+//   K8 min distance: OpenCV accepts candidates greedily in response order.  Equivalent parallel form: a
+//         candidate is accepted iff no ACCEPTED candidate of higher priority lies closer than minDistance;
+//         relax "reject if an accepted stronger neighbour exists / accept if every stronger neighbour is
+//         rejected" to the fixed point over a cell grid of round(minDistance) px (3x3 cell search, as OpenCV's
+//         grid).  Only the accepted set is sorted (k_sort.hip).
+// Candidates live in per-workgroup regions (region b = the local maxima of tile b, count in blk_count[b]):
+// no single-address atomics anywhere on the image-sized passes (one word saturates at ~90 atomics/us on
+// gfx950), and the masked maximum is published with a read-guarded atomicMax.
+// The whole detection is enqueued without host round trips; the host synchronises once, to learn the
+// number of accepted corners.
 #include "icelk_internal.h"
 
 namespace icelk {
@@ -31,44 +38,293 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
-// order-preserving map float -> uint32 (larger float <=> larger key)
+// order-preserving map float -> uint32 (larger float <=> larger key); 0 is below every float
 __device__ __forceinline__ unsigned ordered_key(float v)
 {
     const unsigned b = __float_as_uint(v);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
-__host__ __device__ __forceinline__ float key_to_float(unsigned k)
+__device__ __forceinline__ float key_to_float(unsigned k)
 {
     const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-#if defined(__HIP_DEVICE_COMPILE__)
     return __uint_as_float(b);
-#else
-    float f;
-    memcpy(&f, &b, 4);
-    return f;
-#endif
 }
 
-constexpr int EIG_TW = 64;  // output tile
-constexpr int EIG_TH = 16;
+__device__ __forceinline__ float threshold_of(const unsigned* max_key, double quality)
+{
+    const unsigned mk = *max_key;
+    const double max_val = mk ? (double)key_to_float(mk) : 0.0;
+    return (float)(max_val * quality);
+}
+
+// Sobel (ksize 3) pair scaled as cornerEigenValsVecs does, in OpenCV's operation order:
+//   Dx: row pass [-1 0 1] (exact), column pass (r0 + r2)*k1 + r1*k0
+//   Dy: row pass k1*a + k0*b + k1*c left to right, column pass t2 - t0
+__device__ __forceinline__ void sobel_cov(float a0, float b0, float c0, float a1, float c1, float a2, float b2,
+                                          float c2, float k0, float k1, float& xx, float& xy, float& yy)
+{
+    const float dx = __fadd_rn(__fmul_rn(__fadd_rn(__fsub_rn(c0, a0), __fsub_rn(c2, a2)), k1),
+                               __fmul_rn(__fsub_rn(c1, a1), k0));
+    const float t0 = __fadd_rn(__fadd_rn(__fmul_rn(k1, a0), __fmul_rn(k0, b0)), __fmul_rn(k1, c0));
+    const float t2 = __fadd_rn(__fadd_rn(__fmul_rn(k1, a2), __fmul_rn(k0, b2)), __fmul_rn(k1, c2));
+    const float dy = __fsub_rn(t2, t0);
+    xx = __fmul_rn(dx, dx);
+    xy = __fmul_rn(dx, dy);
+    yy = __fmul_rn(dy, dy);
+}
+
+__device__ __forceinline__ float min_eig_of(double s0, double s1, double s2)
+{
+    const float a = __fmul_rn((float)s0, 0.5f), b = (float)s1, c = __fmul_rn((float)s2, 0.5f);
+    const float d = __fsub_rn(a, c);
+    return __fsub_rn(__fadd_rn(a, c), sqrtf(__fadd_rn(__fmul_rn(d, d), __fmul_rn(b, b))));
+}
+
+// wave-reduce `best` and publish it; the atomic is skipped when the published maximum is already as large
+// (the value only grows, so a stale read can only cause a redundant atomic, never a lost one)
+__device__ __forceinline__ void publish_max(unsigned* max_key, unsigned best, int tid)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned other = __shfl_xor(best, o);
+        best = other > best ? other : best;
+    }
+    if ((tid & 63) == 0 && best > __atomic_load_n(max_key, __ATOMIC_RELAXED)) atomicMax(max_key, best);
+}
+
+// Candidate source: nblk regions of `region` keys each, blk_count[b] valid keys in region b.
+struct CandSrc {
+    const unsigned long long* keys;
+    const int* blk_count;
+    int nblk;
+    int region;
+};
 
 // ------------------------------------------------------------------------------------------------
-// K6.  LDS: cov[3][(TH+bs-1)][(TW+bs-1)] f32, then hs[3][(TH+bs-1)][TW] f64.
+// Fused K6+K7, compile-time blockSize.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_min_eig(const uint8_t* __restrict__ img, int w, int h, int pitch,
-                                                 int bs, float k0, float k1, float* __restrict__ eig,
+template <int BS>
+struct EigCfg {
+    static constexpr int TW = 64, TH = 16;             // outputs per workgroup
+    static constexpr int EW = TW + 2, EH = TH + 2;     // eigenvalues incl. the 1-px ring for the 3x3 test
+    static constexpr int CW = EW + BS - 1, CH = EH + BS - 1;  // covariance positions
+    static constexpr int CWP = (CW + 3) & ~3;          // covariance row pitch (floats)
+    static constexpr int UW = CW + 2, UH = CH + 2;     // u8 source tile
+    static constexpr int UPD = (UW + 2) / 4 + 1;       // its LDS row pitch (dwords, any 4-byte phase)
+    static constexpr int AN = BS / 2;                  // boxFilter anchor
+    static constexpr int RX = 6, RY = 6;               // register blocking of the two sum passes
+    static constexpr int NGX = EW / RX, NGY = EH / RY;
+    static_assert(EW % RX == 0 && EH % RY == 0, "blocking must divide the tile");
+    static constexpr int U_BYTES = (UPD * UH * 4 + 15) & ~15;
+    static constexpr int COV_BYTES = 3 * CH * CWP * 4;
+    static constexpr int A_BYTES = U_BYTES + COV_BYTES;       // later reused for the eigenvalue tile
+    static constexpr int HS_BYTES = 3 * CH * EW * 8;          // later reused for the candidate list
+    static constexpr int LDS_BYTES = A_BYTES + HS_BYTES;
+    static_assert(EW * EH * 4 <= A_BYTES, "eigenvalue tile must fit the dead covariance region");
+};
+
+template <int BS>
+__global__ __launch_bounds__(256) void k_eig_nms(const uint8_t* __restrict__ img, int w, int h, int pitch, float k0,
+                                                 float k1, const uint8_t* __restrict__ mask, int mask_pitch,
+                                                 unsigned* __restrict__ max_key,
+                                                 unsigned long long* __restrict__ raw, int* __restrict__ blk_count,
+                                                 float* __restrict__ eig_out)
+{
+    using C = EigCfg<BS>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* U = reinterpret_cast<uint32_t*>(smem);
+    float* cov = reinterpret_cast<float*>(smem + C::U_BYTES);
+    double* hs = reinterpret_cast<double*>(smem + C::A_BYTES);
+    float* E = reinterpret_cast<float*>(smem);                                  // after the row-sum pass
+    __shared__ int s_list_n;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * C::TW, y0 = blockIdx.y * C::TH;
+    const int ux0 = x0 - 2 - C::AN, uy0 = y0 - 2 - C::AN;   // image coordinate of U(0,0)
+    const bool interior = ux0 >= 0 && uy0 >= 0 && ux0 + C::UW <= w && uy0 + C::UH <= h;
+    constexpr int NQ = C::CWP / 4;
+    constexpr int COVP = C::CH * C::CWP;   // plane stride
+
+    if (interior) {
+        // 1a. stage the source tile as aligned dwords
+        const uint8_t* base = img + (size_t)uy0 * pitch + (ux0 & ~3);
+        for (int i = tid; i < C::UPD * C::UH; i += 256) {
+            const int r = i / C::UPD, c = i - r * C::UPD;
+            U[i] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * c);
+        }
+        __syncthreads();
+        // 1b. covariance products, 4 positions per task
+        const int cs = ux0 & 3;
+        for (int t = tid; t < C::CH * NQ; t += 256) {
+            const int cy = t / NQ, q = t - cy * NQ;
+            int B[3][6];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const uint32_t* p = U + (cy + r) * C::UPD + ((cs + 4 * q) >> 2);
+                const int sh = (cs + 4 * q) & 3;
+                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+                const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, sh), e1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                B[r][0] = e0 & 255; B[r][1] = (e0 >> 8) & 255; B[r][2] = (e0 >> 16) & 255; B[r][3] = e0 >> 24;
+                B[r][4] = e1 & 255; B[r][5] = (e1 >> 8) & 255;
+            }
+            float xx[4], xy[4], yy[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                sobel_cov((float)B[0][i], (float)B[0][i + 1], (float)B[0][i + 2], (float)B[1][i], (float)B[1][i + 2],
+                          (float)B[2][i], (float)B[2][i + 1], (float)B[2][i + 2], k0, k1, xx[i], xy[i], yy[i]);
+            float* c = cov + cy * C::CWP + 4 * q;
+            *reinterpret_cast<float4*>(c) = make_float4(xx[0], xx[1], xx[2], xx[3]);
+            *reinterpret_cast<float4*>(c + COVP) = make_float4(xy[0], xy[1], xy[2], xy[3]);
+            *reinterpret_cast<float4*>(c + 2 * COVP) = make_float4(yy[0], yy[1], yy[2], yy[3]);
+        }
+    } else {
+        // border tiles: covariance at the reflected position (boxFilter reflects the covariance image, Sobel
+        // reflects the source image)
+        for (int i = tid; i < C::CH * C::CW; i += 256) {
+            const int cy = i / C::CW, cx = i - cy * C::CW;
+            const int rx = reflect101(ux0 + 1 + cx, w), ry = reflect101(uy0 + 1 + cy, h);
+            const int xm = reflect101(rx - 1, w), xp = reflect101(rx + 1, w);
+            const int ym = reflect101(ry - 1, h), yp = reflect101(ry + 1, h);
+            const uint8_t* r0 = img + (size_t)ym * pitch;
+            const uint8_t* r1 = img + (size_t)ry * pitch;
+            const uint8_t* r2 = img + (size_t)yp * pitch;
+            float xx, xy, yy;
+            sobel_cov((float)r0[xm], (float)r0[rx], (float)r0[xp], (float)r1[xm], (float)r1[xp], (float)r2[xm],
+                      (float)r2[rx], (float)r2[xp], k0, k1, xx, xy, yy);
+            float* c = cov + cy * C::CWP + cx;
+            c[0] = xx; c[COVP] = xy; c[2 * COVP] = yy;
+        }
+    }
+    __syncthreads();
+
+    // 2. row sums: hs[p][cy][ex] = sum_{k<BS} cov[p][cy][ex+k], left to right, in double
+    constexpr int HSP = C::CH * C::EW;
+    for (int t = tid; t < C::CH * C::NGX; t += 256) {
+        const int cy = t / C::NGX, g = t - cy * C::NGX;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const float* c = cov + p * COVP + cy * C::CWP + g * C::RX;
+            double v[C::RX + BS - 1];
+#pragma unroll
+            for (int i = 0; i < C::RX + BS - 1; i++) v[i] = (double)c[i];
+            double* o = hs + p * HSP + cy * C::EW + g * C::RX;
+#pragma unroll
+            for (int i = 0; i < C::RX; i++) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < BS; k++) s += v[i + k];
+                o[i] = s;
+            }
+        }
+    }
+    __syncthreads();
+
+    // 3. column sums top to bottom, eigenvalue tile (aliases the covariance region), masked maximum
+    unsigned best = 0;
+    for (int t = tid; t < C::EW * C::NGY; t += 256) {
+        const int g = t / C::EW, ex = t - g * C::EW;
+        double v[3][C::RY + BS - 1];
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int i = 0; i < C::RY + BS - 1; i++) v[p][i] = hs[p * HSP + (g * C::RY + i) * C::EW + ex];
+#pragma unroll
+        for (int i = 0; i < C::RY; i++) {
+            double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+            for (int k = 0; k < BS; k++) { s0 += v[0][i + k]; s1 += v[1][i + k]; s2 += v[2][i + k]; }
+            const float e = min_eig_of(s0, s1, s2);
+            const int ey = g * C::RY + i;
+            // E is written only after every thread finished reading hs; cov is dead since the barrier above
+            E[ey * C::EW + ex] = e;
+            const int x = x0 - 1 + ex, y = y0 - 1 + ey;
+            if (ex >= 1 && ex <= C::TW && ey >= 1 && ey <= C::TH && x < w && y < h) {
+                if (eig_out) eig_out[(size_t)y * w + x] = e;
+                if (!mask || mask[(size_t)y * mask_pitch + x]) {
+                    const unsigned k = ordered_key(e);
+                    best = k > best ? k : best;
+                }
+            }
+        }
+    }
+    publish_max(max_key, best, tid);
+    if (tid == 0) s_list_n = 0;
+    __syncthreads();
+
+    // 4. 3x3 non-max test; survivors go straight to this workgroup's region of the candidate buffer
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    unsigned long long* region = raw + (size_t)bid * (C::TW * C::TH);
+    for (int i = tid; i < C::TW * C::TH; i += 256) {
+        const int oy = i / C::TW, ox = i - oy * C::TW;
+        const int x = x0 + ox, y = y0 + oy;
+        if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) continue;
+        const float* e = E + (oy + 1) * C::EW + (ox + 1);
+        const float v = e[0];
+        if (!(v > 0.f)) continue;
+        float m = e[-C::EW - 1];
+        m = fmaxf(m, e[-C::EW]); m = fmaxf(m, e[-C::EW + 1]);
+        m = fmaxf(m, e[-1]); m = fmaxf(m, e[1]);
+        m = fmaxf(m, e[C::EW - 1]); m = fmaxf(m, e[C::EW]); m = fmaxf(m, e[C::EW + 1]);
+        if (v < m) continue;
+        if (mask && !mask[(size_t)y * mask_pitch + x]) continue;
+        region[atomicAdd(&s_list_n, 1)] = ((unsigned long long)ordered_key(v) << 32) | (unsigned)(y * w + x);
+    }
+    __syncthreads();
+    if (tid == 0) blk_count[bid] = s_list_n;
+}
+
+// workgroup-aggregated append: every thread offers at most one key per call; one global atomic per call
+__device__ __forceinline__ void block_append(bool keep, unsigned long long key, unsigned long long* out,
+                                             int* out_count, int* s_cnt, int* s_base)
+{
+    if (threadIdx.x == 0) *s_cnt = 0;
+    __syncthreads();
+    const int pos = keep ? atomicAdd(s_cnt, 1) : 0;
+    __syncthreads();
+    if (threadIdx.x == 0 && *s_cnt) *s_base = atomicAdd(out_count, *s_cnt);
+    __syncthreads();
+    if (keep) out[*s_base + pos] = key;
+    __syncthreads();
+}
+
+// regions -> flat list of the candidates above max * qualityLevel (minDistance < 1 path: everything is sorted)
+__global__ __launch_bounds__(256) void k_flatten(CandSrc src, const unsigned* __restrict__ max_key, double quality,
+                                                 unsigned long long* __restrict__ cand, int* __restrict__ cand_count)
+{
+    __shared__ int s_cnt, s_base;
+    const float thr = threshold_of(max_key, quality);
+    for (int b = blockIdx.x; b < src.nblk; b += gridDim.x) {
+        const int cnt = src.blk_count[b];
+        for (int i0 = 0; i0 < cnt; i0 += 256) {
+            const int i = i0 + threadIdx.x;
+            unsigned long long key = 0;
+            bool keep = false;
+            if (i < cnt) {
+                key = src.keys[(size_t)b * src.region + i];
+                keep = key_to_float((unsigned)(key >> 32)) > thr;
+            }
+            block_append(keep, key, cand, cand_count, &s_cnt, &s_base);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6 generic: any blockSize, writes the eigenvalue map.  LDS: cov[3][eh][ew] f32, hs[3][eh][TW] f64.
+// ------------------------------------------------------------------------------------------------
+constexpr int EIG_TW = 64;
+constexpr int EIG_TH = 16;
+
+__global__ __launch_bounds__(256) void k_min_eig(const uint8_t* __restrict__ img, int w, int h, int pitch, int bs,
+                                                 float k0, float k1, float* __restrict__ eig,
                                                  const uint8_t* __restrict__ mask, int mask_pitch,
                                                  unsigned* __restrict__ max_key)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int anchor = bs / 2;
     const int ew = EIG_TW + bs - 1, eh = EIG_TH + bs - 1;
-    double* hs = reinterpret_cast<double*>(smem);                       // 3 * eh * TW doubles
-    float* cov = reinterpret_cast<float*>(smem + sizeof(double) * 3 * eh * EIG_TW);  // 3 * eh * ew floats
+    double* hs = reinterpret_cast<double*>(smem);
+    float* cov = reinterpret_cast<float*>(smem + sizeof(double) * 3 * eh * EIG_TW);
     const int x0 = blockIdx.x * EIG_TW, y0 = blockIdx.y * EIG_TH;
     const int tid = threadIdx.x;
-
-    // 1. covariance products at the (reflected) extended positions
     for (int i = tid; i < ew * eh; i += 256) {
         const int ey = i / ew, ex = i - ey * ew;
         const int rx = reflect101(x0 - anchor + ex, w), ry = reflect101(y0 - anchor + ey, h);
@@ -77,22 +333,14 @@ __global__ __launch_bounds__(256) void k_min_eig(const uint8_t* __restrict__ img
         const uint8_t* r0 = img + (size_t)ym * pitch;
         const uint8_t* r1 = img + (size_t)ry * pitch;
         const uint8_t* r2 = img + (size_t)yp * pitch;
-        const float a0 = (float)r0[xm], b0 = (float)r0[rx], c0 = (float)r0[xp];
-        const float a1 = (float)r1[xm], c1 = (float)r1[xp];
-        const float a2 = (float)r2[xm], b2 = (float)r2[rx], c2 = (float)r2[xp];
-        // Dx: row pass [-1 0 1] (exact), column pass (r0 + r2)*k1 + r1*k0
-        const float dx = __fadd_rn(__fmul_rn(__fadd_rn(__fsub_rn(c0, a0), __fsub_rn(c2, a2)), k1),
-                                   __fmul_rn(__fsub_rn(c1, a1), k0));
-        // Dy: row pass k1*a + k0*b + k1*c left to right, column pass t2 - t0
-        const float t0 = __fadd_rn(__fadd_rn(__fmul_rn(k1, a0), __fmul_rn(k0, b0)), __fmul_rn(k1, c0));
-        const float t2 = __fadd_rn(__fadd_rn(__fmul_rn(k1, a2), __fmul_rn(k0, b2)), __fmul_rn(k1, c2));
-        const float dy = __fsub_rn(t2, t0);
-        cov[i] = __fmul_rn(dx, dx);
-        cov[ew * eh + i] = __fmul_rn(dx, dy);
-        cov[2 * ew * eh + i] = __fmul_rn(dy, dy);
+        float xx, xy, yy;
+        sobel_cov((float)r0[xm], (float)r0[rx], (float)r0[xp], (float)r1[xm], (float)r1[xp], (float)r2[xm],
+                  (float)r2[rx], (float)r2[xp], k0, k1, xx, xy, yy);
+        cov[i] = xx;
+        cov[ew * eh + i] = xy;
+        cov[2 * ew * eh + i] = yy;
     }
     __syncthreads();
-    // 2. horizontal window sums, left to right, double
     for (int i = tid; i < eh * EIG_TW; i += 256) {
         const int ey = i / EIG_TW, ox = i - ey * EIG_TW;
         const float* c = cov + ey * ew + ox;
@@ -107,8 +355,7 @@ __global__ __launch_bounds__(256) void k_min_eig(const uint8_t* __restrict__ img
         hs[2 * eh * EIG_TW + i] = s2;
     }
     __syncthreads();
-    // 3. vertical sums top to bottom, eigenvalue, masked maximum
-    unsigned best = 0;  // smaller than the key of any float
+    unsigned best = 0;
     for (int i = tid; i < EIG_TH * EIG_TW; i += 256) {
         const int oy = i / EIG_TW, ox = i - oy * EIG_TW;
         const int x = x0 + ox, y = y0 + oy;
@@ -120,130 +367,175 @@ __global__ __launch_bounds__(256) void k_min_eig(const uint8_t* __restrict__ img
             s1 += r[eh * EIG_TW + k * EIG_TW];
             s2 += r[2 * eh * EIG_TW + k * EIG_TW];
         }
-        const float a = __fmul_rn((float)s0, 0.5f), b = (float)s1, c = __fmul_rn((float)s2, 0.5f);
-        const float d = __fsub_rn(a, c);
-        const float v = __fsub_rn(__fadd_rn(a, c), sqrtf(__fadd_rn(__fmul_rn(d, d), __fmul_rn(b, b))));
+        const float v = min_eig_of(s0, s1, s2);
         eig[(size_t)y * w + x] = v;
         if (!mask || mask[(size_t)y * mask_pitch + x]) {
             const unsigned k = ordered_key(v);
             best = k > best ? k : best;
         }
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const unsigned other = __shfl_xor(best, o);
-        best = other > best ? other : best;
-    }
-    if ((tid & 63) == 0 && best) atomicMax(max_key, best);
+    publish_max(max_key, best, tid);
 }
 
-// ------------------------------------------------------------------------------------------------
-// K7.
-// ------------------------------------------------------------------------------------------------
+// K7 generic: threshold + 3x3 dilate equality on the materialised map; a workgroup covers a 256 x 8 pixel band
+// and owns region (blockIdx) of the candidate buffer.
+constexpr int NMS_ROWS = 8;
 __global__ __launch_bounds__(256) void k_nms_collect(const float* __restrict__ eig, int w, int h,
                                                      const uint8_t* __restrict__ mask, int mask_pitch,
                                                      const unsigned* __restrict__ max_key, double quality,
-                                                     unsigned long long* __restrict__ cand,
-                                                     int* __restrict__ cand_count, int cand_cap)
+                                                     unsigned long long* __restrict__ raw, int* __restrict__ blk_count)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x + 1;
-    const int y = blockIdx.y + 1;
-    if (x >= w - 1 || y >= h - 1) return;
-    const unsigned mk = *max_key;
-    const double max_val = mk ? (double)key_to_float(mk) : 0.0;
-    const float thr = (float)(max_val * quality);
-    const float v = eig[(size_t)y * w + x];
-    if (!(v > thr) || v == 0.f) return;
-    if (mask && !mask[(size_t)y * mask_pitch + x]) return;
-    float m = 0.f;  // dilate of the TOZERO-thresholded map (includes the centre)
+    __shared__ int list_n;
+    const int tid = threadIdx.x;
+    if (tid == 0) list_n = 0;
+    __syncthreads();
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    unsigned long long* region = raw + (size_t)bid * (256 * NMS_ROWS);
+    const float thr = threshold_of(max_key, quality);
+    const int x = blockIdx.x * 256 + tid + 1;
+    for (int r = 0; r < NMS_ROWS; r++) {
+        const int y = blockIdx.y * NMS_ROWS + r + 1;
+        if (x >= w - 1 || y >= h - 1) continue;
+        const float v = eig[(size_t)y * w + x];
+        if (!(v > thr) || v == 0.f) continue;
+        if (mask && !mask[(size_t)y * mask_pitch + x]) continue;
+        float m = 0.f;  // dilate of the TOZERO-thresholded map (includes the centre)
 #pragma unroll
-    for (int dy = -1; dy <= 1; dy++)
+        for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
-        for (int dx = -1; dx <= 1; dx++) {
-            float q = eig[(size_t)(y + dy) * w + (x + dx)];
-            q = q > thr ? q : 0.f;
-            m = q > m ? q : m;
-        }
-    if (v != m) return;
-    const int pos = atomicAdd(cand_count, 1);
-    if (pos < cand_cap)
-        cand[pos] = ((unsigned long long)ordered_key(v) << 32) | (unsigned)(y * w + x);
+            for (int dx = -1; dx <= 1; dx++) {
+                float q = eig[(size_t)(y + dy) * w + (x + dx)];
+                q = q > thr ? q : 0.f;
+                m = q > m ? q : m;
+            }
+        if (v != m) continue;
+        region[atomicAdd(&list_n, 1)] = ((unsigned long long)ordered_key(v) << 32) | (unsigned)(y * w + x);
+    }
+    __syncthreads();
+    if (tid == 0) blk_count[bid] = list_n;
 }
 
 // ------------------------------------------------------------------------------------------------
 // K8 helpers.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_cell_count(const unsigned long long* __restrict__ cand, const int* __restrict__ n_ptr, int w,
-                             int cell, int gw, int* __restrict__ cell_count)
+__global__ __launch_bounds__(256) void k_cell_count(CandSrc src, const unsigned* __restrict__ max_key, double quality,
+                                                    int w, int cell, int gw, int* __restrict__ cell_count)
 {
-    const int n = *n_ptr;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned idx = (unsigned)cand[i];
-        const int y = idx / w, x = idx - y * w;
-        atomicAdd(&cell_count[(y / cell) * gw + (x / cell)], 1);
+    const float thr = threshold_of(max_key, quality);
+    for (int b = blockIdx.x; b < src.nblk; b += gridDim.x) {
+        const int cnt = src.blk_count[b];
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            const unsigned long long key = src.keys[(size_t)b * src.region + i];
+            if (!(key_to_float((unsigned)(key >> 32)) > thr)) continue;
+            const unsigned idx = (unsigned)key;
+            const int y = idx / w, x = idx - y * w;
+            atomicAdd(&cell_count[(y / cell) * gw + (x / cell)], 1);
+        }
     }
 }
 
-// single-workgroup exclusive scan: start[i] = sum_{j<i} count[j], start[n] = total
+// exclusive scan, 4096 elements per workgroup: each workgroup first sums everything before its chunk
+// (the count array is L2-resident), then scans its own chunk.  start[n] = total.
+constexpr int SCAN_CHUNK = 4096;
+__device__ __forceinline__ int block_sum_1024(int v, int* sm)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[wave] = v;
+    __syncthreads();
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) t += sm[i];
+    return t;
+}
+
 __global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ count, int* __restrict__ start, int n)
 {
-    __shared__ int part[1024];
+    __shared__ int sm[16];
+    __shared__ int wave_tot[16];
     const int tid = threadIdx.x;
-    const int chunk = (n + 1023) / 1024;
-    const int lo = tid * chunk, hi = min(n, lo + chunk);
-    int s = 0;
-    for (int i = lo; i < hi; i++) s += count[i];
-    part[tid] = s;
+    const int lo = blockIdx.x * SCAN_CHUNK;
+    int pre = 0;
+    for (int i = tid; i < lo; i += 1024) pre += count[i];
+    pre = block_sum_1024(pre, sm);
+    // own chunk: 4 consecutive elements per thread
+    int c[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = lo + 4 * tid + k;
+        c[k] = i < n ? count[i] : 0;
+        s += c[k];
+    }
+    // inclusive scan of s across the workgroup
+    int inc = s;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        int v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    int wbase = 0;
+    for (int i = 0; i < wave; i++) wbase += wave_tot[i];
+    int run = pre + wbase + inc - s;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = lo + 4 * tid + k;
+        if (i < n) start[i] = run;
+        run += c[k];
+        if (i == n - 1) start[n] = run;
     }
-    int run = tid ? part[tid - 1] : 0;
-    for (int i = lo; i < hi; i++) {
-        start[i] = run;
-        run += count[i];
-    }
-    if (tid == 1023) start[n] = part[1023];
+    if (n == 0 && blockIdx.x == 0 && tid == 0) start[0] = 0;
 }
 
-__global__ void k_cell_fill(const unsigned long long* __restrict__ cand, const int* __restrict__ n_ptr, int w,
-                            int cell, int gw, const int* __restrict__ cell_start, int* __restrict__ cell_fill,
-                            unsigned long long* __restrict__ cell_cand, uint8_t* __restrict__ state)
+__global__ __launch_bounds__(256) void k_cell_fill(CandSrc src, const unsigned* __restrict__ max_key, double quality,
+                                                   int w, int cell, int gw, const int* __restrict__ cell_start,
+                                                   int* __restrict__ cell_fill,
+                                                   unsigned long long* __restrict__ cell_cand,
+                                                   uint8_t* __restrict__ state)
 {
-    const int n = *n_ptr;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned long long key = cand[i];
-        const unsigned idx = (unsigned)key;
-        const int y = idx / w, x = idx - y * w;
-        const int c = (y / cell) * gw + (x / cell);
-        const int pos = cell_start[c] + atomicAdd(&cell_fill[c], 1);
-        cell_cand[pos] = key;
-        state[pos] = 0;
+    const float thr = threshold_of(max_key, quality);
+    for (int b = blockIdx.x; b < src.nblk; b += gridDim.x) {
+        const int cnt = src.blk_count[b];
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            const unsigned long long key = src.keys[(size_t)b * src.region + i];
+            if (!(key_to_float((unsigned)(key >> 32)) > thr)) continue;
+            const unsigned idx = (unsigned)key;
+            const int y = idx / w, x = idx - y * w;
+            const int c = (y / cell) * gw + (x / cell);
+            const int pos = cell_start[c] + atomicAdd(&cell_fill[c], 1);
+            cell_cand[pos] = key;
+            state[pos] = 0;
+        }
     }
 }
 
-// One relaxation round.  round_counters[r] counts the candidates still undecided after round r.
-__global__ void k_suppress_round(const unsigned long long* __restrict__ cell_cand, const int* __restrict__ n_ptr,
-                                 int w, int cell, int gw, int gh, const int* __restrict__ cell_start,
-                                 uint8_t* state, double md2, int* __restrict__ round_counters, int r)
+// Relaxation.  A thread owns one candidate and re-examines it up to SUPPRESS_ITERS times within the launch;
+// states are read and written with L1-bypassing (system-scope relaxed) accesses and only ever move
+// 0 -> 1 or 0 -> 2 on final facts, so concurrent progress of other workgroups is picked up as it happens and a
+// stale read merely costs another look.  launch_counters[r] = candidates still undecided after launch r.
+constexpr int SUPPRESS_ITERS = 12;
+__global__ void k_suppress(const unsigned long long* __restrict__ cell_cand, const int* __restrict__ n_ptr,
+                           int w, int cell, int gw, int gh, const int* __restrict__ cell_start, uint8_t* state,
+                           double md2, int* __restrict__ launch_counters, int r)
 {
-    if (r > 0 && round_counters[r - 1] == 0) return;
+    if (r > 0 && launch_counters[r - 1] == 0) return;
     const int n = *n_ptr;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (state[i]) continue;
+        if (__atomic_load_n(&state[i], __ATOMIC_RELAXED)) continue;
         const unsigned long long key = cell_cand[i];
         const unsigned idx = (unsigned)key;
         const int y = idx / w, x = idx - y * w;
         const int xc = x / cell, yc = y / cell;
         const int x1 = max(0, xc - 1), y1 = max(0, yc - 1), x2 = min(gw - 1, xc + 1), y2 = min(gh - 1, yc + 1);
-        bool rejected = false, blocked = false;
-        for (int yy = y1; yy <= y2 && !rejected; yy++)
-            for (int xx = x1; xx <= x2 && !rejected; xx++) {
-                const int c = yy * gw + xx;
-                const int b = cell_start[c], e = cell_start[c + 1];
+        bool decided = false;
+        for (int it = 0; it < SUPPRESS_ITERS && !decided; it++) {
+            bool rejected = false, blocked = false;
+            for (int yy = y1; yy <= y2 && !rejected; yy++) {
+                const int b = cell_start[yy * gw + x1], e = cell_start[yy * gw + x2 + 1];  // the 3 cells are contiguous
                 for (int j = b; j < e; j++) {
                     const unsigned long long kj = cell_cand[j];
                     if (kj <= key) continue;  // only stronger candidates matter (keys are unique)
@@ -256,19 +548,25 @@ __global__ void k_suppress_round(const unsigned long long* __restrict__ cell_can
                     if (sj == 0) blocked = true;
                 }
             }
-        if (rejected) __atomic_store_n(&state[i], (uint8_t)2, __ATOMIC_RELAXED);
-        else if (!blocked) __atomic_store_n(&state[i], (uint8_t)1, __ATOMIC_RELAXED);
-        else atomicAdd(&round_counters[r], 1);
+            if (rejected) { __atomic_store_n(&state[i], (uint8_t)2, __ATOMIC_RELAXED); decided = true; }
+            else if (!blocked) { __atomic_store_n(&state[i], (uint8_t)1, __ATOMIC_RELAXED); decided = true; }
+        }
+        if (!decided) atomicAdd(&launch_counters[r], 1);
     }
 }
 
-__global__ void k_gather_accepted(const unsigned long long* __restrict__ cell_cand, const int* __restrict__ n_ptr,
-                                  const uint8_t* __restrict__ state, unsigned long long* __restrict__ acc,
-                                  int* __restrict__ acc_count)
+__global__ __launch_bounds__(256) void k_gather_accepted(const unsigned long long* __restrict__ cell_cand,
+                                                         const int* __restrict__ n_ptr,
+                                                         const uint8_t* __restrict__ state,
+                                                         unsigned long long* __restrict__ acc,
+                                                         int* __restrict__ acc_count)
 {
+    __shared__ int s_cnt, s_base;
     const int n = *n_ptr;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (state[i] == 1) acc[atomicAdd(acc_count, 1)] = cell_cand[i];
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+        const int i = i0 + threadIdx.x;
+        const bool keep = i < n && state[i] == 1;
+        block_append(keep, keep ? cell_cand[i] : 0ull, acc, acc_count, &s_cnt, &s_base);
     }
 }
 
@@ -282,21 +580,36 @@ __global__ void k_emit(const unsigned long long* __restrict__ keys, int n, int w
     xy[2 * i + 1] = (float)y;
 }
 
-}  // namespace
-
-void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig, const uint8_t* mask,
-                    int mask_pitch, unsigned* max_key)
+void sobel_scale(int block_size, float* k0, float* k1)
 {
     double scale = (double)(1 << 2) * block_size;
     scale *= 255.0;
     scale = 1.0 / scale;
-    const float k1 = (float)(1.0 * scale), k0 = (float)(2.0 * scale);
-    const int ew = EIG_TW + block_size - 1, eh = EIG_TH + block_size - 1;
-    const size_t lds = sizeof(double) * 3 * eh * EIG_TW + sizeof(float) * 3 * eh * ew;
-    dim3 grid((img.w + EIG_TW - 1) / EIG_TW, (img.h + EIG_TH - 1) / EIG_TH);
-    hipLaunchKernelGGL(k_min_eig, grid, dim3(256), lds, s, img.ptr, img.w, img.h, img.pitch, block_size, k0, k1,
-                       eig, mask, mask_pitch, max_key);
+    *k1 = (float)(1.0 * scale);
+    *k0 = (float)(2.0 * scale);
 }
+
+template <int BS>
+void launch_fused(hipStream_t s, const Level& img, float k0, float k1, const uint8_t* mask, int mask_pitch,
+                  unsigned* max_key, unsigned long long* raw, int* blk_count, float* eig_out, CandSrc* src)
+{
+    using C = EigCfg<BS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eig_nms<BS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C::LDS_BYTES);
+        attr_set = true;
+    }
+    dim3 grid((img.w + C::TW - 1) / C::TW, (img.h + C::TH - 1) / C::TH);
+    hipLaunchKernelGGL((k_eig_nms<BS>), grid, dim3(256), C::LDS_BYTES, s, img.ptr, img.w, img.h, img.pitch, k0, k1,
+                       mask, mask_pitch, max_key, raw, blk_count, eig_out);
+    src->keys = raw;
+    src->blk_count = blk_count;
+    src->nblk = (int)(grid.x * grid.y);
+    src->region = C::TW * C::TH;
+}
+
+}  // namespace
 
 size_t min_eig_lds_bytes(int block_size)
 {
@@ -304,55 +617,134 @@ size_t min_eig_lds_bytes(int block_size)
     return sizeof(double) * 3 * eh * EIG_TW + sizeof(float) * 3 * eh * ew;
 }
 
-void launch_nms_collect(hipStream_t s, const float* eig, int w, int h, const uint8_t* mask, int mask_pitch,
-                        const unsigned* max_key, double quality, unsigned long long* cand, int* cand_count,
-                        int cand_cap)
+bool fused_block_size(int bs) { return bs == 3 || bs == 5 || bs == 7 || bs == 10; }
+
+// capacity (in keys) the region layout needs for a w x h frame, whichever kernel produces the candidates
+size_t candidate_capacity(int w, int h)
 {
-    if (w < 3 || h < 3) return;
-    dim3 grid((w - 2 + 255) / 256, h - 2);
-    hipLaunchKernelGGL(k_nms_collect, grid, dim3(256), 0, s, eig, w, h, mask, mask_pitch, max_key, quality, cand,
-                       cand_count, cand_cap);
+    const size_t fused = (size_t)((w + 63) / 64) * ((h + 15) / 16) * (64 * 16);
+    const size_t generic = (size_t)((w + 255) / 256) * ((h + NMS_ROWS - 1) / NMS_ROWS) * (256 * NMS_ROWS);
+    return (fused > generic ? fused : generic) + 1024;
+}
+size_t candidate_blocks(int w, int h) { return (size_t)((w + 63) / 64) * ((h + 15) / 16) + 16; }
+
+// K6 alone, writing the map with the any-blockSize kernel.
+void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig, const uint8_t* mask,
+                    int mask_pitch, unsigned* max_key)
+{
+    float k0, k1;
+    sobel_scale(block_size, &k0, &k1);
+    const size_t lds = min_eig_lds_bytes(block_size);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_min_eig), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        attr_lds = lds;
+    }
+    dim3 grid((img.w + EIG_TW - 1) / EIG_TW, (img.h + EIG_TH - 1) / EIG_TH);
+    hipLaunchKernelGGL(k_min_eig, grid, dim3(256), lds, s, img.ptr, img.w, img.h, img.pitch, block_size, k0, k1, eig,
+                       mask, mask_pitch, max_key);
 }
 
-// Greedy-equivalent min-distance selection.  D.cand / D.cand_count hold the candidates.  On return
-// D.acc / D.acc_count hold the accepted keys (unsorted).  Synchronises the stream (reads the
-// round counters).
-int run_min_distance(hipStream_t s, DetectScratch& D, int w, int h, int n_cand_upper, double min_distance,
-                     std::string& err)
+static CandSrc src_of(const DetectScratch& D)
+{
+    CandSrc c;
+    c.keys = D.acc_sorted;
+    c.blk_count = D.blk_count;
+    c.nblk = D.src_nblk;
+    c.region = D.src_region;
+    return c;
+}
+
+// Candidate collection (K6+K7) into regions of D.acc_sorted (stream order, no host sync).
+void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
+                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null)
+{
+    hipMemsetAsync(D.max_key, 0, sizeof(unsigned), s);
+    unsigned long long* raw = D.acc_sorted;
+    CandSrc g_src{};
+    if (!use_generic && fused_block_size(block_size)) {
+        float k0, k1;
+        sobel_scale(block_size, &k0, &k1);
+        switch (block_size) {
+            case 3: launch_fused<3>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
+            case 5: launch_fused<5>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
+            case 7: launch_fused<7>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
+            default: launch_fused<10>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
+        }
+    } else {
+        launch_min_eig(s, img, block_size, D.eig, mask, mask_pitch, D.max_key);
+        g_src.keys = raw;
+        g_src.blk_count = D.blk_count;
+        g_src.nblk = 0;
+        g_src.region = 256 * NMS_ROWS;
+        if (img.w >= 3 && img.h >= 3) {
+            dim3 grid((img.w - 2 + 255) / 256, (img.h - 2 + NMS_ROWS - 1) / NMS_ROWS);
+            hipLaunchKernelGGL(k_nms_collect, grid, dim3(256), 0, s, D.eig, img.w, img.h, mask, mask_pitch, D.max_key,
+                               quality, raw, D.blk_count);
+            g_src.nblk = (int)(grid.x * grid.y);
+        }
+    }
+    D.src_nblk = g_src.nblk;
+    D.src_region = g_src.region;
+}
+
+// minDistance < 1: every candidate above the threshold, flat in D.cand / D.cand_count
+void launch_flatten(hipStream_t s, DetectScratch& D, double quality)
+{
+    hipMemsetAsync(D.cand_count, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_flatten, dim3(512), dim3(256), 0, s, src_of(D), D.max_key, quality, D.cand, D.cand_count);
+}
+
+// Greedy-equivalent min-distance selection, fully enqueued (no host round trip): candidate regions ->
+// D.acc (unsorted accepted keys), D.acc_count; the number of thresholded candidates ends in
+// D.cell_start[ncell].  D.undecided[kSuppressLaunches-1] != 0 afterwards means "not converged, call
+// continue_min_distance".
+constexpr int kSuppressLaunches = 4;
+static void suppress_launches(hipStream_t s, DetectScratch& D, int w, int h, double min_distance)
+{
+    const int cell = (int)lrint(min_distance);
+    const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+    const double md2 = min_distance * min_distance;
+    hipMemsetAsync(D.undecided, 0, sizeof(int) * kSuppressLaunches, s);
+    for (int r = 0; r < kSuppressLaunches; r++)
+        hipLaunchKernelGGL(k_suppress, dim3(1024), dim3(256), 0, s, D.cell_cand, D.cell_start + gw * gh, w, cell, gw,
+                           gh, D.cell_start, D.state, md2, D.undecided, r);
+}
+
+static void gather_launch(hipStream_t s, DetectScratch& D, int ncell)
+{
+    hipMemsetAsync(D.acc_count, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_gather_accepted, dim3(256), dim3(256), 0, s, D.cell_cand, D.cell_start + ncell, D.state, D.acc,
+                       D.acc_count);
+}
+
+void launch_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double min_distance, double quality)
 {
     const int cell = (int)lrint(min_distance);
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     const int ncell = gw * gh;
-    const double md2 = min_distance * min_distance;
     hipMemsetAsync(D.cell_count, 0, sizeof(int) * (size_t)(ncell + 1), s);
     hipMemsetAsync(D.cell_fill, 0, sizeof(int) * (size_t)ncell, s);
-    hipMemsetAsync(D.acc_count, 0, sizeof(int), s);
-    const int blocks = max(1, min(2048, (n_cand_upper + 255) / 256));
-    hipLaunchKernelGGL(k_cell_count, dim3(blocks), dim3(256), 0, s, D.cand, D.cand_count, w, cell, gw,
-                       D.cell_count);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, D.cell_count, D.cell_start, ncell);
-    hipLaunchKernelGGL(k_cell_fill, dim3(blocks), dim3(256), 0, s, D.cand, D.cand_count, w, cell, gw, D.cell_start,
+    hipLaunchKernelGGL(k_cell_count, dim3(1024), dim3(256), 0, s, src_of(D), D.max_key, quality, w, cell, gw, D.cell_count);
+    hipLaunchKernelGGL(k_scan, dim3((ncell + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(1024), 0, s, D.cell_count,
+                       D.cell_start, ncell);
+    hipLaunchKernelGGL(k_cell_fill, dim3(1024), dim3(256), 0, s, src_of(D), D.max_key, quality, w, cell, gw, D.cell_start,
                        D.cell_fill, D.cell_cand, D.state);
-    constexpr int kBatch = 8;
-    int last = 1;
-    for (int guard = 0; guard < 4096 && last != 0; guard++) {
-        hipMemsetAsync(D.undecided, 0, sizeof(int) * kBatch, s);
-        for (int r = 0; r < kBatch; r++)
-            hipLaunchKernelGGL(k_suppress_round, dim3(blocks), dim3(256), 0, s, D.cell_cand, D.cand_count, w, cell,
-                               gw, gh, D.cell_start, D.state, md2, D.undecided, r);
-        int counters[kBatch];
-        hipError_t e = hipMemcpyAsync(counters, D.undecided, sizeof(counters), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { err = hipGetErrorString(e); return ICELK_EHIP; }
-        last = counters[kBatch - 1];
-        for (int r = 0; r < kBatch; r++)
-            if (counters[r] == 0) { last = 0; break; }
-    }
-    if (last != 0) { err = "min-distance suppression did not converge"; return ICELK_EHIP; }
-    hipLaunchKernelGGL(k_gather_accepted, dim3(blocks), dim3(256), 0, s, D.cell_cand, D.cand_count, D.state, D.acc,
-                       D.acc_count);
-    return ICELK_OK;
+    suppress_launches(s, D, w, h, min_distance);
+    gather_launch(s, D, ncell);
 }
+
+// more relaxation launches + a fresh gather (only when the first batch left candidates undecided)
+void continue_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double min_distance)
+{
+    const int cell = (int)lrint(min_distance);
+    const int ncell = ((w + cell - 1) / cell) * ((h + cell - 1) / cell);
+    suppress_launches(s, D, w, h, min_distance);
+    gather_launch(s, D, ncell);
+}
+
+int suppress_launch_count() { return kSuppressLaunches; }
 
 void launch_emit_corners(hipStream_t s, const unsigned long long* keys, int n, int w, float* xy)
 {

@@ -72,11 +72,14 @@ void launch_bgr2gray(hipStream_t s, const uint8_t* src, int src_pitch, uint8_t* 
 //
 // A lane owns a strip of 4 output columns x PD_ROWS output rows.  Per source row it needs the 11
 // bytes at columns 8q-2 .. 8q+8; it loads the 16 aligned bytes 8q-4 .. 8q+11 as one dwordx4
-// (neighbouring lanes overlap by 8 bytes -> L1 hits, HBM sees every byte once), forms the four
-// horizontal sums, and keeps the last five rows of sums in registers.  Every second source row one
-// output row (4 bytes = 1 dword per lane, 256 B per wave) is stored.
+// (neighbouring lanes overlap by 8 bytes -> L1 hits, HBM sees every byte once) and forms the four
+// horizontal sums; the 2*PD_ROWS+3 row loads of a strip are all in flight together.  One output
+// row is 4 bytes = 1 dword per lane, 256 B per wave.
 // ------------------------------------------------------------------------------------------------
-constexpr int PD_ROWS = 8;
+constexpr int PD_ROWS = 4;
+constexpr int PD_SRC = 2 * PD_ROWS + 3;  // source rows a lane touches
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 struct HSum4 {
     int v[4];
@@ -93,9 +96,8 @@ __device__ __forceinline__ HSum4 hsum_from_bytes(const int* b)  // b[0..10] = co
     return r;
 }
 
-__device__ __forceinline__ HSum4 hsum_fast(const uint8_t* row, int q)
+__device__ __forceinline__ HSum4 hsum_from_u4(const u32x4_a4 u)  // the 16 bytes at columns 8q-4 .. 8q+11
 {
-    const uint4 u = *reinterpret_cast<const uint4*>(row + 8 * q - 4);
     int b[11];
     b[0] = (u.x >> 16) & 255; b[1] = u.x >> 24;
     b[2] = u.y & 255; b[3] = (u.y >> 8) & 255; b[4] = (u.y >> 16) & 255; b[5] = u.y >> 24;
@@ -112,8 +114,8 @@ __device__ __forceinline__ HSum4 hsum_border(const uint8_t* row, int q, int w)
     return hsum_from_bytes(b);
 }
 
-__global__ __launch_bounds__(256) void k_pyrdown(const uint8_t* __restrict__ src, int sw, int sh, int spitch,
-                                                 uint8_t* __restrict__ dst, int dw, int dh, int dpitch)
+__global__ __launch_bounds__(64) void k_pyrdown(const uint8_t* __restrict__ src, int sw, int sh, int spitch,
+                                                uint8_t* __restrict__ dst, int dw, int dh, int dpitch)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 output columns
     const int oy0 = blockIdx.y * PD_ROWS;
@@ -121,37 +123,40 @@ __global__ __launch_bounds__(256) void k_pyrdown(const uint8_t* __restrict__ src
     // the 16-byte load covers columns 8q-4 .. 8q+11: fast path only when fully inside the row
     const bool fast = (q > 0) && (8 * q + 12 <= sw);
 
-    HSum4 r[5];
-    // source rows 2*oy0-2 .. ; prime the window with the first three rows
+    // all source rows of the strip are requested before the first one is used (latency, not issue, bound)
+    HSum4 r[PD_SRC];
+    if (fast) {
+        u32x4_a4 u[PD_SRC];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const uint8_t* row = src + (size_t)reflect101(2 * oy0 - 2 + k, sh) * spitch;
-        r[k + 2] = fast ? hsum_fast(row, q) : hsum_border(row, q, sw);
+        for (int k = 0; k < PD_SRC; k++) {
+            const uint8_t* row = src + (size_t)reflect101(2 * oy0 - 2 + k, sh) * spitch;
+            u[k] = *reinterpret_cast<const u32x4_a4*>(row + 8 * q - 4);
+        }
+#pragma unroll
+        for (int k = 0; k < PD_SRC; k++) r[k] = hsum_from_u4(u[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < PD_SRC; k++) {
+            const uint8_t* row = src + (size_t)reflect101(2 * oy0 - 2 + k, sh) * spitch;
+            r[k] = hsum_border(row, q, sw);
+        }
     }
 #pragma unroll
     for (int j = 0; j < PD_ROWS; j++) {
         const int oy = oy0 + j;
-        if (oy >= dh) break;
-        r[0] = r[2]; r[1] = r[3]; r[2] = r[4];
-        {
-            const uint8_t* row = src + (size_t)reflect101(2 * oy + 1, sh) * spitch;
-            r[3] = fast ? hsum_fast(row, q) : hsum_border(row, q, sw);
-        }
-        {
-            const uint8_t* row = src + (size_t)reflect101(2 * oy + 2, sh) * spitch;
-            r[4] = fast ? hsum_fast(row, q) : hsum_border(row, q, sw);
-        }
-        uint32_t out = 0;
+        if (oy < dh) {
+            uint32_t out = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int v = r[0].v[i] + r[4].v[i] + 4 * (r[1].v[i] + r[3].v[i]) + 6 * r[2].v[i];
-            out |= (uint32_t)((v + 128) >> 8) << (8 * i);
-        }
-        uint8_t* d = dst + (size_t)oy * dpitch + 4 * q;
-        if (4 * q + 4 <= dw) {
-            *reinterpret_cast<uint32_t*>(d) = out;
-        } else {
-            for (int i = 0; 4 * q + i < dw; i++) d[i] = (uint8_t)(out >> (8 * i));
+            for (int i = 0; i < 4; i++) {
+                int v = r[2 * j].v[i] + r[2 * j + 4].v[i] + 4 * (r[2 * j + 1].v[i] + r[2 * j + 3].v[i]) + 6 * r[2 * j + 2].v[i];
+                out |= (uint32_t)((v + 128) >> 8) << (8 * i);
+            }
+            uint8_t* d = dst + (size_t)oy * dpitch + 4 * q;
+            if (4 * q + 4 <= dw) {
+                *reinterpret_cast<uint32_t*>(d) = out;
+            } else {
+                for (int i = 0; 4 * q + i < dw; i++) d[i] = (uint8_t)(out >> (8 * i));
+            }
         }
     }
 }

@@ -34,36 +34,39 @@ __global__ __launch_bounds__(1024) void k_compact(const float* __restrict__ p1, 
                                                   float* __restrict__ quality, int vert, int max_vert,
                                                   unsigned long long* __restrict__ tracked_total)
 {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
+    // tiles of 1024 consecutive tracks: coalesced loads, ballot prefix inside a wave, 16 wave totals in LDS
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = *n_in;
-    const int chunk = (n + 1023) / 1024;
-    const int lo = min(n, tid * chunk), hi = min(n, lo + chunk);
-    int cnt = 0;
-    for (int i = lo; i < hi; i++) cnt += valid[i] ? 1 : 0;
-    part[tid] = cnt;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = tid >= o ? part[tid - o] : 0;
+    int running = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const bool keep = i < n && valid[i];
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wave_tot[wave] = __popcll(m);
         __syncthreads();
-        part[tid] += v;
+        int wbase = 0, tile_total = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int t = wave_tot[k];
+            wbase += k < wave ? t : 0;
+            tile_total += t;
+        }
+        if (keep) {
+            const int j = running + wbase + __popcll(m & ((1ull << lane) - 1ull));
+            const int o = origin_in[i];
+            const float x = p1[2 * i], y = p1[2 * i + 1];
+            live_out[2 * j] = x; live_out[2 * j + 1] = y;
+            origin_out[j] = o;
+            tracks[((size_t)o * max_vert + vert) * 2] = x;
+            tracks[((size_t)o * max_vert + vert) * 2 + 1] = y;
+            quality[(size_t)o * (max_vert - 1) + (vert - 1)] = dist[i];
+        }
+        running += tile_total;
         __syncthreads();
     }
-    int j = tid ? part[tid - 1] : 0;
-    for (int i = lo; i < hi; i++) {
-        if (!valid[i]) continue;
-        const int o = origin_in[i];
-        const float x = p1[2 * i], y = p1[2 * i + 1];
-        live_out[2 * j] = x; live_out[2 * j + 1] = y;
-        origin_out[j] = o;
-        tracks[((size_t)o * max_vert + vert) * 2] = x;
-        tracks[((size_t)o * max_vert + vert) * 2 + 1] = y;
-        quality[(size_t)o * (max_vert - 1) + (vert - 1)] = dist[i];
-        j++;
-    }
-    __syncthreads();
-    if (tid == 1023) {
-        *n_out = part[1023];
+    if (tid == 0) {
+        *n_out = running;
         *tracked_total += (unsigned long long)n;
     }
 }

@@ -205,3 +205,80 @@ def test_large_motion_restage(ctx, orc, synth):
         q = orc.pyrlk(img0, img1, pts, None, win, ml, (3, 30, 0.01))
         for x, z in zip(a, q):
             assert np.array_equal(x.view(np.uint8), z.view(np.uint8))
+
+
+@pytest.mark.parametrize("bs", [3, 5, 7, 10])
+def test_fused_corner_kernel_equals_generic(ctx, orc, synth, bs, monkeypatch):
+    """k_eig_nms<BS> (no eigenvalue map in HBM) vs k_min_eig + k_nms_collect vs oracle."""
+    img = synth.frame(777, 500, 5, 9, 31)
+    mask = np.zeros_like(img)
+    mask[3:450, 10:700] = 1
+    ctx.upload_gray(0, img)
+    ctx.set_mask(mask)
+    for use_mask in (False, True):
+        fused = ctx.good_features(0, 0, 0.01, 5, use_mask, bs)
+        fused_map = ctx.min_eig_map(0, bs)
+        monkeypatch.setenv("ICELK_GENERIC_CORNERS", "1")
+        generic = ctx.good_features(0, 0, 0.01, 5, use_mask, bs)
+        generic_map = ctx.min_eig_map(0, bs)
+        monkeypatch.delenv("ICELK_GENERIC_CORNERS")
+        ref = orc.good_features(img, 0, 0.01, 5, mask if use_mask else None, bs)
+        assert np.array_equal(fused, generic) and np.array_equal(fused, ref)
+        assert np.array_equal(fused_map.view(np.uint32), generic_map.view(np.uint32))
+    ctx.set_mask(None)
+
+
+def test_corner_ties_and_plateaus(ctx, orc):
+    """Periodic image: many exactly equal responses -> tie-break by raster index must match."""
+    yy, xx = np.mgrid[0:240, 0:320]
+    img = (((xx // 8) + (yy // 8)) % 2 * 200 + 20).astype(np.uint8)
+    ctx.upload_gray(0, img)
+    for md in (0, 1, 4, 10):
+        got = ctx.good_features(0, 0, 0.05, md, False, 3)
+        ref = orc.good_features(img, 0, 0.05, md, None, 3)
+        assert (got is None) == (ref is None)
+        if got is not None:
+            assert np.array_equal(got, ref), md
+
+
+class _OracleCv:
+    """cv2-shaped facade over the oracle, to drive the reference-shaped loop on the CPU."""
+
+    def __init__(self, orc):
+        self.o = orc
+
+    def calcOpticalFlowPyrLK(self, a, b, p0, p1, **kw):
+        return self.o.pyrlk(a, b, p0, p1, **kw)
+
+    def goodFeaturesToTrack(self, img, mask=None, **kw):
+        return self.o.good_features(img, kw["maxCorners"], kw["qualityLevel"], kw["minDistance"], mask,
+                                    kw.get("blockSize", 3))
+
+
+@pytest.mark.parametrize("track_len", [1, 2, 3])
+def test_segment_tracker_equals_reference_loop(orc, synth, track_len):
+    """Device-resident loop (SegmentTracker) vs the list-of-lists loop of s1:307-450 run on the oracle."""
+    from iceberg_tracking_code_amd import SegmentTracker, run_reference_loop
+    w, h, nfr = 400, 300, 8
+    frames, _ = synth.sequence(w, h, nfr, seed=77, max_step_px=2.5)
+    mask = np.zeros((h, w), np.uint8)
+    mask[20:280, 30:390] = 255
+    fp = dict(maxCorners=400, qualityLevel=0.007, minDistance=10, blockSize=10)
+    lk = dict(winSize=(35, 35), maxLevel=4, criteria=(3, 25, 0.03))
+    ref = run_reference_loop(frames, track_len, fp, lk, mask=mask, cv=_OracleCv(orc))
+    trk = SegmentTracker(w, h, track_len, fp, lk, mask=mask, max_pts=4096)
+    got = []
+    for f in frames:
+        seg = trk.push(f)
+        if seg is not None:
+            got.append(seg)
+    trk.close()
+    assert len(got) == len(ref) and len(ref) >= 2
+    for (gf, gt, gq), (rf, rt, rq) in zip(got, ref):
+        rt = np.asarray(rt, np.float32).reshape(len(rt), -1, 2)
+        rq = np.asarray(rq, np.float32).reshape(len(rq), -1)
+        assert gf == rf
+        assert gt.shape == rt.shape and gt.shape[1] == track_len + 1
+        assert np.array_equal(gt.view(np.uint32), rt.view(np.uint32))
+        assert np.array_equal(gq.view(np.uint32), rq.view(np.uint32))
+        assert len(gt) > 100
