@@ -47,6 +47,7 @@ SIGNATURES = {
     "icelk_min_eig_map": (C.c_int, [handle_p, C.c_int, C.c_int, f32p, C.c_int]),
     "icelk_good_features": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, f32p,
                                       C.c_int, i32p]),
+    "icelk_detect_stats": (C.c_int, [handle_p, i32p, i32p]),
     "icelk_seg_detect": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, i32p]),
     "icelk_seg_track": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_double, C.c_double, C.c_float, i32p]),

@@ -180,6 +180,11 @@ class Context:
             return None
         return out[:n.value].reshape(-1, 1, 2).copy()
 
+    def detect_stats(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self._ck(self._lib.icelk_detect_stats(self._h, C.byref(a), C.byref(b)))
+        return dict(candidates=a.value, accepted=b.value)
+
     # -- device-resident segment state ----------------------------------------------------------
     def seg_detect(self, slot, maxCorners, qualityLevel, minDistance, use_mask=False, blockSize=3):
         n = C.c_int(0)

@@ -51,6 +51,8 @@ struct Ctx {
     int seg_cur = 0, seg_vert = 0, seg_upper = 0;
     bool seg_active = false;
 
+    int last_candidates = 0, last_accepted = 0;   // of the latest detection
+
     // profiling
     bool prof = false;
     std::vector<ProfEvt> evts;
@@ -303,8 +305,15 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
     DetectScratch& D = c->D;
     *n_out = 0;
     const bool generic = getenv("ICELK_GENERIC_CORNERS") != nullptr;
+    size_t ncell_all = 0;
+    if (min_distance >= 1) {
+        const int cell0 = (int)lrint(min_distance);
+        ncell_all = (size_t)((w + cell0 - 1) / cell0) * ((h + cell0 - 1) / cell0);
+        if (ncell_all + 1 > c->ncell_cap) FAIL(c, ICELK_ECAP, "cell grid larger than allocated");
+    }
     {
         ProfScope p(c, K_EIG);
+        launch_detect_reset(c->stream, D, (int)ncell_all);
         launch_candidates(c->stream, D, s.lv[0], block_size, mask, c->mask_pitch, quality, generic, nullptr);
     }
     rc = check_launch(c, "corner candidates");
@@ -340,14 +349,17 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
             if ((rc = fetch())) return rc;
         }
         total = counts[1];
+        c->last_candidates = counts[0];
+        c->last_accepted = total;
         if (total == 0) return ICELK_OK;
         sort_keys_desc(c->stream, D, D.acc, D.acc_sorted, total);
         sorted = D.acc_sorted;
     } else {
         launch_flatten(c->stream, D, quality);
-        HIPCHK(c, hipMemsetAsync(D.undecided, 0, sizeof(int) * 8, c->stream));
         if ((rc = fetch())) return rc;
         total = counts[0];
+        c->last_candidates = total;
+        c->last_accepted = total;
         if (total == 0) return ICELK_OK;
         sort_keys_desc(c->stream, D, D.cand, D.cell_cand, total);
         sorted = D.cell_cand;
@@ -437,7 +449,7 @@ const char* icelk_last_error(icelk_t* h)
 int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, icelk_t** out)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!out || max_w <= 0 || max_h <= 0 || n_slots <= 0 || max_pts <= 0) {
+    if (!out || max_w <= 0 || max_h <= 0 || max_w > 65535 || max_h > 65535 || n_slots <= 0 || max_pts <= 0) {
         g_create_err = "icelk_create: bad argument";
         return ICELK_EARG;
     }
@@ -855,10 +867,10 @@ int icelk_min_eig_map(icelk_t* h, int slot, int block_size, float* host_out, int
     if (rc) return rc;
     {
         ProfScope p(c, K_EIG);
+        launch_detect_reset(c->stream, c->D, 0);
         if (fused_block_size(block_size) && !getenv("ICELK_GENERIC_CORNERS")) {
             launch_candidates(c->stream, c->D, s.lv[0], block_size, nullptr, 0, 1.0, false, c->D.eig);
         } else {
-            HIPCHK(c, hipMemsetAsync(c->D.max_key, 0, sizeof(unsigned), c->stream));
             launch_min_eig(c->stream, s.lv[0], block_size, c->D.eig, nullptr, 0, c->D.max_key);
         }
     }
@@ -885,6 +897,15 @@ int icelk_good_features(icelk_t* h, int slot, int use_mask, int max_corners, dou
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     *out_n = n;
+    return ICELK_OK;
+}
+
+int icelk_detect_stats(icelk_t* h, int* n_candidates, int* n_accepted)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    if (n_candidates) *n_candidates = c->last_candidates;
+    if (n_accepted) *n_accepted = c->last_accepted;
     return ICELK_OK;
 }
 

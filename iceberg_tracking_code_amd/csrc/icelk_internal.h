@@ -114,6 +114,7 @@ struct DetectScratch {
 void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig, const uint8_t* mask,
                     int mask_pitch, unsigned* max_key);
 bool fused_block_size(int bs);
+void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell);   // must precede launch_candidates
 // K6+K7: local maxima into per-workgroup regions of D.acc_sorted (stream order, no host sync)
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
                        int mask_pitch, double quality, bool use_generic, float* eig_out_or_null);

@@ -8,7 +8,7 @@
 //   K6+K7 fused (k_eig_nms<BS>, blockSize 3/5/7/10): one tile per workgroup, everything through LDS:
 //         u8 tile -> Sobel -> covariance products -> blockSize^2 box sums (ordered double sums, register
 //         blocked) -> min eigenvalue (+1 px halo) -> 3x3 non-max test, mask, 1-px border -> local maxima
-//         appended as 64-bit keys (response key << 32 | raster index), plus the masked maximum of the map
+//         appended as 64-bit keys (response key << 32 | y << 16 | x), plus the masked maximum of the map
 //         (order-preserving atomicMax).  Neither OpenCV's f32 Dx/Dy/covariance images (5 x 4 B/px) nor the
 //         eigenvalue map itself ever exist in HBM: 1 B/px is read, ~8 B per local maximum written.
 //         The quality threshold (max * qualityLevel) is applied to the candidate list afterwards
@@ -49,6 +49,10 @@ __device__ __forceinline__ float key_to_float(unsigned k)
     const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
     return __uint_as_float(b);
 }
+
+// low half of a candidate key: (y << 16) | x orders exactly like the raster address y*w + x (the tie-break of
+// OpenCV's greaterThanPtr) and needs no division to unpack; frames are < 65536 px on either side
+__device__ __forceinline__ unsigned pack_xy(int x, int y) { return ((unsigned)y << 16) | (unsigned)x; }
 
 __device__ __forceinline__ float threshold_of(const unsigned* max_key, double quality)
 {
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256) void k_eig_nms(const uint8_t* __restrict__ img
         m = fmaxf(m, e[C::EW - 1]); m = fmaxf(m, e[C::EW]); m = fmaxf(m, e[C::EW + 1]);
         if (v < m) continue;
         if (mask && !mask[(size_t)y * mask_pitch + x]) continue;
-        region[atomicAdd(&s_list_n, 1)] = ((unsigned long long)ordered_key(v) << 32) | (unsigned)(y * w + x);
+        region[atomicAdd(&s_list_n, 1)] = ((unsigned long long)ordered_key(v) << 32) | pack_xy(x, y);
     }
     __syncthreads();
     if (tid == 0) blk_count[bid] = s_list_n;
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(256) void k_nms_collect(const float* __restrict__ e
                 m = q > m ? q : m;
             }
         if (v != m) continue;
-        region[atomicAdd(&list_n, 1)] = ((unsigned long long)ordered_key(v) << 32) | (unsigned)(y * w + x);
+        region[atomicAdd(&list_n, 1)] = ((unsigned long long)ordered_key(v) << 32) | pack_xy(x, y);
     }
     __syncthreads();
     if (tid == 0) blk_count[bid] = list_n;
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256) void k_cell_count(CandSrc src, const unsigned*
             const unsigned long long key = src.keys[(size_t)b * src.region + i];
             if (!(key_to_float((unsigned)(key >> 32)) > thr)) continue;
             const unsigned idx = (unsigned)key;
-            const int y = idx / w, x = idx - y * w;
+            const int y = (int)(idx >> 16), x = (int)(idx & 0xffffu);
             atomicAdd(&cell_count[(y / cell) * gw + (x / cell)], 1);
         }
     }
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256) void k_cell_fill(CandSrc src, const unsigned* 
             const unsigned long long key = src.keys[(size_t)b * src.region + i];
             if (!(key_to_float((unsigned)(key >> 32)) > thr)) continue;
             const unsigned idx = (unsigned)key;
-            const int y = idx / w, x = idx - y * w;
+            const int y = (int)(idx >> 16), x = (int)(idx & 0xffffu);
             const int c = (y / cell) * gw + (x / cell);
             const int pos = cell_start[c] + atomicAdd(&cell_fill[c], 1);
             cell_cand[pos] = key;
@@ -513,46 +517,81 @@ __global__ __launch_bounds__(256) void k_cell_fill(CandSrc src, const unsigned* 
     }
 }
 
-// Relaxation.  A thread owns one candidate and re-examines it up to SUPPRESS_ITERS times within the launch;
-// states are read and written with L1-bypassing (system-scope relaxed) accesses and only ever move
-// 0 -> 1 or 0 -> 2 on final facts, so concurrent progress of other workgroups is picked up as it happens and a
-// stale read merely costs another look.  launch_counters[r] = candidates still undecided after launch r.
-constexpr int SUPPRESS_ITERS = 12;
-__global__ void k_suppress(const unsigned long long* __restrict__ cell_cand, const int* __restrict__ n_ptr,
-                           int w, int cell, int gw, int gh, const int* __restrict__ cell_start, uint8_t* state,
-                           double md2, int* __restrict__ launch_counters, int r)
+// Relaxation.  A thread owns one candidate.  Its first look scans the 3x3 cells and keeps the indices of the
+// stronger candidates within minDistance that are still undecided (its "blockers") in LDS; after that it only
+// polls those.  States are read and written with L1-bypassing (system-scope relaxed) accesses and only ever
+// move 0 -> 1 or 0 -> 2 on final facts, so progress made by other workgroups is seen as it happens and a stale
+// read merely costs another poll.  Spins are bounded; launch_counters[r] = candidates still undecided after
+// launch r, and launch r+1 picks them up (it returns at once when that count is zero).
+constexpr int SUP_K = 24;
+constexpr int SUP_SPINS = 48;
+__global__ __launch_bounds__(256) void k_suppress(const unsigned long long* __restrict__ cell_cand,
+                                                  const int* __restrict__ n_ptr, int cell, int gw, int gh,
+                                                  const int* __restrict__ cell_start, uint8_t* state, double md2,
+                                                  int* __restrict__ launch_counters, int r)
 {
+    __shared__ int blockers[SUP_K * 256];
     if (r > 0 && launch_counters[r - 1] == 0) return;
     const int n = *n_ptr;
+    int* mine = blockers + threadIdx.x;   // entry q at mine[q * 256]: conflict-free
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (__atomic_load_n(&state[i], __ATOMIC_RELAXED)) continue;
         const unsigned long long key = cell_cand[i];
         const unsigned idx = (unsigned)key;
-        const int y = idx / w, x = idx - y * w;
+        const int y = (int)(idx >> 16), x = (int)(idx & 0xffffu);
         const int xc = x / cell, yc = y / cell;
         const int x1 = max(0, xc - 1), y1 = max(0, yc - 1), x2 = min(gw - 1, xc + 1), y2 = min(gh - 1, yc + 1);
-        bool decided = false;
-        for (int it = 0; it < SUPPRESS_ITERS && !decided; it++) {
-            bool rejected = false, blocked = false;
-            for (int yy = y1; yy <= y2 && !rejected; yy++) {
-                const int b = cell_start[yy * gw + x1], e = cell_start[yy * gw + x2 + 1];  // the 3 cells are contiguous
-                for (int j = b; j < e; j++) {
-                    const unsigned long long kj = cell_cand[j];
-                    if (kj <= key) continue;  // only stronger candidates matter (keys are unique)
-                    const unsigned ij = (unsigned)kj;
-                    const int yj = ij / w, xj = ij - yj * w;
-                    const float dx = (float)(x - xj), dy = (float)(y - yj);
-                    if (!((double)(dx * dx + dy * dy) < md2)) continue;
-                    const uint8_t sj = __atomic_load_n(&state[j], __ATOMIC_RELAXED);
-                    if (sj == 1) { rejected = true; break; }
-                    if (sj == 0) blocked = true;
+        int cnt = 0;
+        bool rejected = false, overflow = false;
+        for (int yy = y1; yy <= y2 && !rejected; yy++) {
+            const int b = cell_start[yy * gw + x1], e = cell_start[yy * gw + x2 + 1];  // the 3 cells are contiguous
+            for (int j = b; j < e; j++) {
+                const unsigned long long kj = cell_cand[j];
+                if (kj <= key) continue;  // only stronger candidates matter (keys are unique)
+                const unsigned ij = (unsigned)kj;
+                const int yj = (int)(ij >> 16), xj = (int)(ij & 0xffffu);
+                const float dx = (float)(x - xj), dy = (float)(y - yj);
+                if (!((double)(dx * dx + dy * dy) < md2)) continue;
+                const uint8_t sj = __atomic_load_n(&state[j], __ATOMIC_RELAXED);
+                if (sj == 1) { rejected = true; break; }
+                if (sj == 0) {
+                    if (cnt < SUP_K) mine[256 * cnt++] = j;
+                    else overflow = true;
                 }
             }
+        }
+        bool decided = false;
+        if (rejected) { __atomic_store_n(&state[i], (uint8_t)2, __ATOMIC_RELAXED); decided = true; }
+        else if (cnt == 0 && !overflow) { __atomic_store_n(&state[i], (uint8_t)1, __ATOMIC_RELAXED); decided = true; }
+        for (int spin = 0; spin < SUP_SPINS && !decided && !overflow; spin++) {
+            __builtin_amdgcn_s_sleep(8);
+            int k = 0;
+            for (int q = 0; q < cnt; q++) {
+                const int j = mine[256 * q];
+                const uint8_t sj = __atomic_load_n(&state[j], __ATOMIC_RELAXED);
+                if (sj == 1) { rejected = true; break; }
+                if (sj == 0) mine[256 * k++] = j;
+            }
+            cnt = k;
             if (rejected) { __atomic_store_n(&state[i], (uint8_t)2, __ATOMIC_RELAXED); decided = true; }
-            else if (!blocked) { __atomic_store_n(&state[i], (uint8_t)1, __ATOMIC_RELAXED); decided = true; }
+            else if (cnt == 0) { __atomic_store_n(&state[i], (uint8_t)1, __ATOMIC_RELAXED); decided = true; }
         }
         if (!decided) atomicAdd(&launch_counters[r], 1);
     }
+}
+
+// zero every counter a detection uses, in one launch (each hipMemsetAsync is a ~5 us kernel of its own)
+__global__ void k_detect_reset(int* __restrict__ cell_count, int* __restrict__ cell_fill, int ncell,
+                               int* __restrict__ undecided, int* __restrict__ acc_count,
+                               int* __restrict__ cand_count, unsigned* __restrict__ max_key)
+{
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = i0; i <= ncell; i += gridDim.x * blockDim.x) {
+        cell_count[i] = 0;
+        if (i < ncell) cell_fill[i] = 0;
+    }
+    if (i0 < 8) undecided[i0] = 0;
+    if (i0 == 0) { *acc_count = 0; *cand_count = 0; *max_key = 0; }
 }
 
 __global__ __launch_bounds__(256) void k_gather_accepted(const unsigned long long* __restrict__ cell_cand,
@@ -575,7 +614,7 @@ __global__ void k_emit(const unsigned long long* __restrict__ keys, int n, int w
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned idx = (unsigned)keys[i];
-    const int y = idx / w, x = idx - y * w;
+    const int y = (int)(idx >> 16), x = (int)(idx & 0xffffu);
     xy[2 * i] = (float)x;
     xy[2 * i + 1] = (float)y;
 }
@@ -656,11 +695,17 @@ static CandSrc src_of(const DetectScratch& D)
     return c;
 }
 
+// First launch of every detection: zero the counters (ncell = 0 when minDistance < 1).
+void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell)
+{
+    hipLaunchKernelGGL(k_detect_reset, dim3((ncell + 256) / 256 < 512 ? (ncell + 256) / 256 : 512), dim3(256), 0, s,
+                       D.cell_count, D.cell_fill, ncell, D.undecided, D.acc_count, D.cand_count, D.max_key);
+}
+
 // Candidate collection (K6+K7) into regions of D.acc_sorted (stream order, no host sync).
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
                        int mask_pitch, double quality, bool use_generic, float* eig_out_or_null)
 {
-    hipMemsetAsync(D.max_key, 0, sizeof(unsigned), s);
     unsigned long long* raw = D.acc_sorted;
     CandSrc g_src{};
     if (!use_generic && fused_block_size(block_size)) {
@@ -692,7 +737,6 @@ void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int bl
 // minDistance < 1: every candidate above the threshold, flat in D.cand / D.cand_count
 void launch_flatten(hipStream_t s, DetectScratch& D, double quality)
 {
-    hipMemsetAsync(D.cand_count, 0, sizeof(int), s);
     hipLaunchKernelGGL(k_flatten, dim3(512), dim3(256), 0, s, src_of(D), D.max_key, quality, D.cand, D.cand_count);
 }
 
@@ -706,15 +750,13 @@ static void suppress_launches(hipStream_t s, DetectScratch& D, int w, int h, dou
     const int cell = (int)lrint(min_distance);
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     const double md2 = min_distance * min_distance;
-    hipMemsetAsync(D.undecided, 0, sizeof(int) * kSuppressLaunches, s);
     for (int r = 0; r < kSuppressLaunches; r++)
-        hipLaunchKernelGGL(k_suppress, dim3(1024), dim3(256), 0, s, D.cell_cand, D.cell_start + gw * gh, w, cell, gw,
-                           gh, D.cell_start, D.state, md2, D.undecided, r);
+        hipLaunchKernelGGL(k_suppress, dim3(1024), dim3(256), 0, s, D.cell_cand, D.cell_start + gw * gh, cell, gw, gh,
+                           D.cell_start, D.state, md2, D.undecided, r);
 }
 
 static void gather_launch(hipStream_t s, DetectScratch& D, int ncell)
 {
-    hipMemsetAsync(D.acc_count, 0, sizeof(int), s);
     hipLaunchKernelGGL(k_gather_accepted, dim3(256), dim3(256), 0, s, D.cell_cand, D.cell_start + ncell, D.state, D.acc,
                        D.acc_count);
 }
@@ -724,8 +766,6 @@ void launch_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double m
     const int cell = (int)lrint(min_distance);
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     const int ncell = gw * gh;
-    hipMemsetAsync(D.cell_count, 0, sizeof(int) * (size_t)(ncell + 1), s);
-    hipMemsetAsync(D.cell_fill, 0, sizeof(int) * (size_t)ncell, s);
     hipLaunchKernelGGL(k_cell_count, dim3(1024), dim3(256), 0, s, src_of(D), D.max_key, quality, w, cell, gw, D.cell_count);
     hipLaunchKernelGGL(k_scan, dim3((ncell + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(1024), 0, s, D.cell_count,
                        D.cell_start, ncell);
@@ -740,6 +780,8 @@ void continue_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double
 {
     const int cell = (int)lrint(min_distance);
     const int ncell = ((w + cell - 1) / cell) * ((h + cell - 1) / cell);
+    hipMemsetAsync(D.undecided, 0, sizeof(int) * 8, s);
+    hipMemsetAsync(D.acc_count, 0, sizeof(int), s);
     suppress_launches(s, D, w, h, min_distance);
     gather_launch(s, D, ncell);
 }

@@ -1,4 +1,4 @@
-// k_sort.hip -- descending sort of 64-bit corner keys (response bits << 32 | raster index).
+// k_sort.hip -- descending sort of 64-bit corner keys (response key << 32 | y << 16 | x).
 //
 // This is the std::sort(tmpCorners, greaterThanPtr()) step of cv2.goodFeaturesToTrack
 // (s1_lucaskanade_tracking.py:437), applied only to the ACCEPTED corners (see

@@ -53,7 +53,7 @@ typedef struct icelk_ctx icelk_t;
 int icelk_version(void);
 /* Text of the last error on this handle (or of the last failed icelk_create when h == NULL). */
 const char* icelk_last_error(icelk_t* h);
-/* One handle per GPU.  max_w/max_h bound the frame size, n_slots the resident frames,
+/* One handle per GPU.  max_w/max_h (<= 65535) bound the frame size, n_slots the resident frames,
  * max_pts the features per call (maxCorners / len(tracks)). */
 int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, icelk_t** out);
 int icelk_destroy(icelk_t* h);
@@ -112,6 +112,10 @@ int icelk_min_eig_map(icelk_t* h, int slot, int block_size, float* host_out, int
  * *out_n == 0 corresponds to cv2 returning None (guarded at s1:445). */
 int icelk_good_features(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level,
                         double min_distance, int block_size, float* out_xy, int cap, int* out_n);
+
+/* Work counters of the latest detection on this handle: local maxima above the quality threshold, and
+ * corners surviving the minDistance rule (before the maxCorners cut). */
+int icelk_detect_stats(icelk_t* h, int* n_candidates, int* n_accepted);
 
 /* ---- device-resident segment state: the `tracks` / `trackquality` lists of s1:299-300,335-359 --
  * A segment starts at a detection frame (counter % track_len == 0, s1:362,437-448) and is extended
