@@ -9,11 +9,19 @@
 //   * lane = one ROW SEGMENT of the window (S <= 8 contiguous pixels of one window row): 21x21 -> 63
 //     segments of 7 px, one per lane.  A lane reads its pixels from LDS as aligned dwords and realigns
 //     them with v_alignbyte, 6 ds_read_b32 per iteration instead of 28 ds_read_u8.
-//   * the Scharr derivative of the template is formed in registers, separably, from the 4 source rows a
-//     segment touches; nothing but the u8 source patch and the u8 search tile ever sits in LDS.
+//   * pixels are widened to 16-bit PAIRS (v_perm_b32) and every bilinear tap pair is one
+//     v_dot2_i32_i16 against a packed weight pair (w00|w01, w10|w11): a sample costs 2 dot2 + 1 shift;
+//     the rounding constant and the template value ride in the dot2 accumulator.
+//   * the Scharr derivative of the template is formed in registers with packed 16-bit math
+//     (v_pk_add/mad/sub_u16, two columns per instruction) from the 4 source rows a segment touches;
+//     nothing but the u8 source patch and the u8 search tile ever sits in LDS.
+//   * the VALU issue slot (one wave64 instruction per 4 cycles per SIMD) is what bounds this kernel,
+//     so the design goal is instructions per sample, not bytes.
 //   * tiles are staged as aligned dwords, all global loads of a level (template patch AND search tile)
 //     issued before the first one is waited for; divisions by the tile pitch are by constants.
 //   * the five sums are exact integers reduced through the DPP network (lk_common.h), no LDS round trips.
+#include <type_traits>
+
 #include "lk_common.h"
 
 namespace icelk {
@@ -99,22 +107,49 @@ __device__ __forceinline__ bool tile_inside(const Level& L, int x0, int y0, int 
     return x0 >= 0 && y0 >= 0 && x0 + tw <= L.w && y0 + th <= L.h;
 }
 
-// NB bytes starting at byte offset `off` of an LDS row, as ints
-template <int NB>
-__device__ __forceinline__ void row_bytes(const uint32_t* row, int off, int (&out)[NB])
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s as_v2s(uint32_t x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_cast(uint32_t, x); }
+
+// NX stream-aligned dwords (bytes 0 .. 4*NX-1) starting at byte offset `off` of an LDS row
+template <int NX>
+__device__ __forceinline__ void row_dwords(const uint32_t* row, int off, uint32_t (&X)[NX])
 {
-    constexpr int ND = (NB + 3 + 3) / 4;  // dwords that can be touched
     const uint32_t* p = row + (off >> 2);
     const int sh = off & 3;
-    uint32_t d[ND];
+    uint32_t d[NX + 1];
 #pragma unroll
-    for (int i = 0; i < ND; i++) d[i] = p[i];
+    for (int i = 0; i <= NX; i++) d[i] = p[i];
 #pragma unroll
-    for (int i = 0; i < (NB + 3) / 4; i++) {
-        const uint32_t a = __builtin_amdgcn_alignbyte(d[i + 1 < ND ? i + 1 : i], d[i], sh);
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (4 * i + k < NB) out[4 * i + k] = (int)((a >> (8 * k)) & 255u);
+    for (int i = 0; i < NX; i++) X[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+}
+
+// bytes (M, M+1) of the stream widened to a pair of 16-bit lanes: (byte M) | (byte M+1) << 16
+template <int M, int NX>
+__device__ __forceinline__ v2s byte_pair(const uint32_t (&X)[NX])
+{
+    constexpr int i = M / 4, r = M % 4;
+    static_assert(i < NX && (r < 3 || i + 1 < NX), "pair outside the loaded dwords");
+    if constexpr (r == 0) return as_v2s(__builtin_amdgcn_perm(0u, X[i], 0x0c010c00u));
+    else if constexpr (r == 1) return as_v2s(__builtin_amdgcn_perm(0u, X[i], 0x0c020c01u));
+    else if constexpr (r == 2) return as_v2s(__builtin_amdgcn_perm(0u, X[i], 0x0c030c02u));
+    else return as_v2s(__builtin_amdgcn_perm(X[i + 1 < NX ? i + 1 : i], X[i], 0x0c040c03u));
+}
+
+// (a.y, b.x): the pair one 16-bit lane further along
+__device__ __forceinline__ v2s pair_shift(v2s a, v2s b)
+{
+    return as_v2s(__builtin_amdgcn_alignbit(as_u32(b), as_u32(a), 16));
+}
+
+__device__ __forceinline__ int dot2(v2s a, v2s b, int c) { return __builtin_amdgcn_sdot2(a, b, c, false); }
+
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
     }
 }
 
@@ -127,6 +162,8 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
     constexpr int R = kMargin;
     const float half_x = (WW - 1) * 0.5f, half_y = (WH - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
+    // exact wave sums: the grouped form needs (pixels per lane) * (group size) * (max term) < 2^31
+    constexpr bool kSmall = C::TPL * S <= 8;
 
     // this lane's row segments
     int trow[C::TPL], tcol[C::TPL], tlen[C::TPL];
@@ -153,7 +190,7 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
         if (level == P.top_level) { sx = px; sy = py; }
         else { sx = sx * 2.f; sy = sy * 2.f; }
         px -= half_x; py -= half_y;
-        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        const int ipx = uni((int)floorf(px)), ipy = uni((int)floorf(py));
         if (ipx < -WW || ipx >= LI.w || ipy < -WH || ipy >= LI.h) {
             if (level == 0) { Rz.status = 0; Rz.err = 0.f; }
             continue;
@@ -167,7 +204,7 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
         const int ix0 = ipx - 1, iy0 = ipy - 1;
         const bool i_inside = tile_inside(LI, ix0, iy0, C::ITW, C::ITH);
         {
-            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            const int inx = uni((int)floorf(nx)), iny = uni((int)floorf(ny));
             const bool j_ok = !(inx < -WW || inx >= LJ.w || iny < -WH || iny >= LJ.h);
             const int tjx = inx - R, tjy = iny - R;
             const bool j_inside = j_ok && tile_inside(LJ, tjx, tjy, C::JTW, C::JTH);
@@ -184,66 +221,111 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
             __syncthreads();
         }
 
-        // ---- template patch into registers: I (x32), Ix, Iy ------------------------------------------
-        int Iv[C::TPL][S], Ixv[C::TPL][S], Iyv[C::TPL][S];
+        // ---- template patch into registers ---------------------------------------------------------
+        //   Ineg = 256 - (I << 9): the template value pre-loaded into the dot2 accumulator of the residual
+        //   Ixv, Iyv = bilinear Scharr derivatives (int16 range)
+        const v2s W0 = {(short)wi.w00, (short)wi.w01}, W1 = {(short)wi.w10, (short)wi.w11};
+        int Ineg[C::TPL][S], Ixv[C::TPL][S], Iyv[C::TPL][S];
         int a11 = 0, a12 = 0, a22 = 0;
         const int ics = ix0 & 3;
 #pragma unroll
         for (int k = 0; k < C::TPL; k++) {
-            int Bv[4][S + 3];
+            constexpr int NP = (S + 4) / 2;   // even-aligned column pairs covering columns 0 .. S+2
+            constexpr int ND = (S + 2) / 2;   // derivative pairs covering derivative columns 0 .. S
+            v2s E[4][NP];
+            uint32_t X1[3], X2[3];            // aligned dwords of source rows 1 and 2 (for the I samples)
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                row_bytes<S + 3>(ldsI + (trow[k] + r) * C::IPD, ics + tcol[k], Bv[r]);
-            int dxv[2][S + 1], dyv[2][S + 1];
+            for (int r = 0; r < 4; r++) {
+                uint32_t X[3];
+                row_dwords<3>(ldsI + (trow[k] + r) * C::IPD, ics + tcol[k], X);
+                static_for<NP>([&](auto kk) { E[r][kk] = byte_pair<2 * kk, 3>(X); });
+                if (r == 1) { X1[0] = X[0]; X1[1] = X[1]; X1[2] = X[2]; }
+                if (r == 2) { X2[0] = X[0]; X2[1] = X[1]; X2[2] = X[2]; }
+            }
+            // Scharr, two columns per instruction: t0 = 3*(a + c) + 10*b, t1 = c - a down the rows, then
+            // dx = t0[i+2] - t0[i], dy = 3*(t1[i+2] + t1[i]) + 10*t1[i+1] along the row
+            v2s dxp[2][ND], dyp[2][ND];
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                int t0[S + 3], t1[S + 3];
+                v2s t0[NP], t1[NP];
 #pragma unroll
-                for (int j = 0; j < S + 3; j++) {
-                    t0[j] = (Bv[r][j] + Bv[r + 2][j]) * 3 + Bv[r + 1][j] * 10;
-                    t1[j] = Bv[r + 2][j] - Bv[r][j];
+                for (int q = 0; q < NP; q++) {
+                    t0[q] = (E[r][q] + E[r + 2][q]) * (short)3 + E[r + 1][q] * (short)10;
+                    t1[q] = E[r + 2][q] - E[r][q];
                 }
 #pragma unroll
-                for (int i = 0; i < S + 1; i++) {
-                    dxv[r][i] = t0[i + 2] - t0[i];
-                    dyv[r][i] = (t1[i + 2] + t1[i]) * 3 + t1[i + 1] * 10;
+                for (int d = 0; d < ND; d++) {
+                    dxp[r][d] = t0[d + 1] - t0[d];
+                    dyp[r][d] = (t1[d + 1] + t1[d]) * (short)3 + pair_shift(t1[d], t1[d + 1]) * (short)10;
                 }
                 if (!i_inside) {
                     // derivative image is zero outside the frame (BORDER_CONSTANT), SURVEY.md A.4
                     const int gy = ipy + trow[k] + r;
+                    const bool row_in = gy >= 0 && gy < LI.h;
 #pragma unroll
-                    for (int i = 0; i < S + 1; i++) {
-                        const int gx = ipx + tcol[k] + i;
-                        if (gx < 0 || gx >= LI.w || gy < 0 || gy >= LI.h) { dxv[r][i] = 0; dyv[r][i] = 0; }
+                    for (int d = 0; d < ND; d++) {
+                        const int gx = ipx + tcol[k] + 2 * d;
+                        const bool in0 = row_in && gx >= 0 && gx < LI.w, in1 = row_in && gx + 1 >= 0 && gx + 1 < LI.w;
+                        const uint32_t m = (in0 ? 0xffffu : 0u) | (in1 ? 0xffff0000u : 0u);
+                        dxp[r][d] = as_v2s(as_u32(dxp[r][d]) & m);
+                        dyp[r][d] = as_v2s(as_u32(dyp[r][d]) & m);
                     }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < S; j++) {
-                const bool on = j < tlen[k];
-                const int iv = descale(Bv[1][j + 1] * wi.w00 + Bv[1][j + 2] * wi.w01 + Bv[2][j + 1] * wi.w10 +
-                                       Bv[2][j + 2] * wi.w11, W_BITS - 5);
-                const int ixv = descale(dxv[0][j] * wi.w00 + dxv[0][j + 1] * wi.w01 + dxv[1][j] * wi.w10 +
-                                        dxv[1][j + 1] * wi.w11, W_BITS);
-                const int iyv = descale(dyv[0][j] * wi.w00 + dyv[0][j + 1] * wi.w01 + dyv[1][j] * wi.w10 +
-                                        dyv[1][j + 1] * wi.w11, W_BITS);
-                Iv[k][j] = on ? iv : 0;
-                Ixv[k][j] = on ? ixv : 0;
-                Iyv[k][j] = on ? iyv : 0;
-                a11 += Ixv[k][j] * Ixv[k][j];
-                a12 += Ixv[k][j] * Iyv[k][j];
-                a22 += Iyv[k][j] * Iyv[k][j];
-            }
+            static_for<S>([&](auto jj) {
+                constexpr int j = jj;
+                // I sample: source columns (j+1, j+2) of rows 1 and 2
+                const v2s s1 = byte_pair<j + 1, 3>(X1), s2 = byte_pair<j + 1, 3>(X2);
+                const int iv = dot2(s2, W1, dot2(s1, W0, 1 << (W_BITS - 6))) >> (W_BITS - 5);
+                // derivative samples: derivative columns (j, j+1) of derivative rows 0 and 1
+                v2s gx0, gx1, gy0, gy1;
+                if constexpr (j % 2 == 0) {
+                    gx0 = dxp[0][j / 2]; gx1 = dxp[1][j / 2]; gy0 = dyp[0][j / 2]; gy1 = dyp[1][j / 2];
+                } else {
+                    gx0 = pair_shift(dxp[0][j / 2], dxp[0][j / 2 + 1]); gx1 = pair_shift(dxp[1][j / 2], dxp[1][j / 2 + 1]);
+                    gy0 = pair_shift(dyp[0][j / 2], dyp[0][j / 2 + 1]); gy1 = pair_shift(dyp[1][j / 2], dyp[1][j / 2 + 1]);
+                }
+                int ixv = dot2(gx1, W1, dot2(gx0, W0, 1 << (W_BITS - 1))) >> W_BITS;
+                int iyv = dot2(gy1, W1, dot2(gy0, W0, 1 << (W_BITS - 1))) >> W_BITS;
+                int ineg = (1 << (W_BITS - 6)) - (iv << (W_BITS - 5));
+                if constexpr (WW % S != 0) {
+                    const bool on = j < tlen[k];
+                    ixv = on ? ixv : 0;
+                    iyv = on ? iyv : 0;
+                } else if constexpr (C::NTASK % 64 != 0) {
+                    const bool on = tlen[k] != 0;
+                    ixv = on ? ixv : 0;
+                    iyv = on ? iyv : 0;
+                }
+                Ineg[k][j] = ineg;
+                Ixv[k][j] = ixv;
+                Iyv[k][j] = iyv;
+                a11 += __mul24(ixv, ixv);
+                a12 += __mul24(ixv, iyv);
+                a22 += __mul24(iyv, iyv);
+            });
         }
-        const float A11 = (float)wave_sum_exact(a11) * FLT_SCALE;
-        const float A12 = (float)wave_sum_exact(a12) * FLT_SCALE;
-        const float A22 = (float)wave_sum_exact(a22) * FLT_SCALE;
+        // |Ix*Ix| <= 4080^2 per pixel: 16-lane sums fit int32 while a lane holds <= 8 pixels
+        const float A11 = i64_to_float(sum_pick<kSmall, 16>(a11)) * FLT_SCALE;
+        const float A12 = i64_to_float(sum_pick<kSmall, 16>(a12)) * FLT_SCALE;
+        const float A22 = i64_to_float(sum_pick<kSmall, 16>(a22)) * FLT_SCALE;
         float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
         const float dif = __fsub_rn(A11, A22);
         const float rad = __fadd_rn(__fmul_rn(dif, dif), __fmul_rn(__fmul_rn(4.f, A12), A12));
-        const float minEig = __fdiv_rn(__fsub_rn(__fadd_rn(A22, A11), sqrtf(rad)), (float)(2 * WW * WH));
-        if (P.flags & ICELK_FLAG_MIN_EIGENVALS) Rz.err = minEig;
-        if (minEig < P.min_eig_thr || D < 1.1920928955078125e-07f) {
+        const float tr = __fadd_rn(A22, A11);
+        // The exact (correctly rounded sqrt and divide) minEig is only needed when it is reported or close
+        // to the threshold: the hardware-approximate value differs from it by a few ulp of `tr` / (2wh).
+        const float approx = (tr - __builtin_amdgcn_sqrtf(rad)) * (1.f / (float)(2 * WW * WH));
+        const bool clear_pass = approx > P.min_eig_thr + tr * 2e-6f && !(P.flags & ICELK_FLAG_MIN_EIGENVALS);
+        if (!uni(clear_pass)) {
+            const float minEig = __fdiv_rn(__fsub_rn(tr, sqrtf(rad)), (float)(2 * WW * WH));
+            if (P.flags & ICELK_FLAG_MIN_EIGENVALS) Rz.err = minEig;
+            if (minEig < P.min_eig_thr) {
+                if (level == 0) Rz.status = 0;
+                continue;
+            }
+        }
+        if (D < 1.1920928955078125e-07f) {
             if (level == 0) Rz.status = 0;
             continue;
         }
@@ -252,7 +334,7 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
         // ---- iterations ---------------------------------------------------------------------------
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < P.max_count; j++) {
-            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            const int inx = uni((int)floorf(nx)), iny = uni((int)floorf(ny));
             if (inx < -WW || inx >= LJ.w || iny < -WH || iny >= LJ.h) {
                 if (level == 0) Rz.status = 0;
                 break;
@@ -271,24 +353,27 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
                 staged = true;
             }
             const Weights wj = bilinear_weights(nx - (float)inx, ny - (float)iny);
+            const v2s V0 = {(short)wj.w00, (short)wj.w01}, V1 = {(short)wj.w10, (short)wj.w11};
             const int joff = (jx0 & 3) + (inx - jx0);
             const uint32_t* jrow0 = ldsJ + (iny - jy0) * C::JPD;
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int k = 0; k < C::TPL; k++) {
-                int J0[S + 1], J1[S + 1];
-                row_bytes<S + 1>(jrow0 + trow[k] * C::JPD, joff + tcol[k], J0);
-                row_bytes<S + 1>(jrow0 + (trow[k] + 1) * C::JPD, joff + tcol[k], J1);
-#pragma unroll
-                for (int q = 0; q < S; q++) {
-                    const int diff = descale(J0[q] * wj.w00 + J0[q + 1] * wj.w01 + J1[q] * wj.w10 + J1[q + 1] * wj.w11,
-                                             W_BITS - 5) - Iv[k][q];
-                    b1 += diff * Ixv[k][q];
-                    b2 += diff * Iyv[k][q];
-                }
+                constexpr int NXJ = (S + 1 + 3) / 4;
+                uint32_t Y0[NXJ], Y1[NXJ];
+                row_dwords<NXJ>(jrow0 + trow[k] * C::JPD, joff + tcol[k], Y0);
+                row_dwords<NXJ>(jrow0 + (trow[k] + 1) * C::JPD, joff + tcol[k], Y1);
+                static_for<S>([&](auto qq) {
+                    constexpr int q = qq;
+                    // ((J bilinear + 256) >> 9) - I, with 256 - (I << 9) as the accumulator seed
+                    const int diff = dot2(byte_pair<q, NXJ>(Y1), V1, dot2(byte_pair<q, NXJ>(Y0), V0, Ineg[k][q])) >> (W_BITS - 5);
+                    b1 += __mul24(diff, Ixv[k][q]);
+                    b2 += __mul24(diff, Iyv[k][q]);
+                });
             }
-            const float fb1 = (float)wave_sum_exact(b1) * FLT_SCALE;
-            const float fb2 = (float)wave_sum_exact(b2) * FLT_SCALE;
+            // |diff*Ix| <= 8160*4080 per pixel: 8-lane sums fit int32 while a lane holds <= 8 pixels
+            const float fb1 = i64_to_float(sum_pick<kSmall, 8>(b1)) * FLT_SCALE;
+            const float fb2 = i64_to_float(sum_pick<kSmall, 8>(b2)) * FLT_SCALE;
             const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
             const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
             nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
@@ -305,7 +390,7 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
         // ---- residual error at level 0 ----------------------------------------------------------------
         if (Rz.status && level == 0 && !(P.flags & ICELK_FLAG_MIN_EIGENVALS)) {
             const float qx = sx - half_x, qy = sy - half_y;
-            const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
+            const int iqx = uni((int)floorf(qx)), iqy = uni((int)floorf(qy));
             if (iqx < -WW || iqx >= LJ.w || iqy < -WH || iqy >= LJ.h) {
                 Rz.status = 0;
                 continue;
@@ -324,22 +409,23 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
                 staged = true;
             }
             const Weights we = bilinear_weights(qx - (float)iqx, qy - (float)iqy);
+            const v2s V0 = {(short)we.w00, (short)we.w01}, V1 = {(short)we.w10, (short)we.w11};
             const int joff = (jx0 & 3) + (iqx - jx0);
             const uint32_t* jrow0 = ldsJ + (iqy - jy0) * C::JPD;
             int es = 0;
 #pragma unroll
             for (int k = 0; k < C::TPL; k++) {
-                int J0[S + 1], J1[S + 1];
-                row_bytes<S + 1>(jrow0 + trow[k] * C::JPD, joff + tcol[k], J0);
-                row_bytes<S + 1>(jrow0 + (trow[k] + 1) * C::JPD, joff + tcol[k], J1);
-#pragma unroll
-                for (int q = 0; q < S; q++) {
-                    const int diff = descale(J0[q] * we.w00 + J0[q + 1] * we.w01 + J1[q] * we.w10 + J1[q + 1] * we.w11,
-                                             W_BITS - 5) - Iv[k][q];
+                constexpr int NXJ = (S + 1 + 3) / 4;
+                uint32_t Y0[NXJ], Y1[NXJ];
+                row_dwords<NXJ>(jrow0 + trow[k] * C::JPD, joff + tcol[k], Y0);
+                row_dwords<NXJ>(jrow0 + (trow[k] + 1) * C::JPD, joff + tcol[k], Y1);
+                static_for<S>([&](auto qq) {
+                    constexpr int q = qq;
+                    const int diff = dot2(byte_pair<q, NXJ>(Y1), V1, dot2(byte_pair<q, NXJ>(Y0), V0, Ineg[k][q])) >> (W_BITS - 5);
                     es += q < tlen[k] ? (diff < 0 ? -diff : diff) : 0;
-                }
+                });
             }
-            const float errval = (float)wave_sum_exact(es);
+            const float errval = i64_to_float(sum_pick<kSmall, 8>(es));
             Rz.err = __fdiv_rn(__fmul_rn(errval, 1.f), (float)(32 * WW * WH));
         }
     }
@@ -349,7 +435,7 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
 }
 
 template <int WW, int WH, bool FB>
-__global__ __launch_bounds__(64) void k_lk_fast(Pyramid PI, Pyramid PJ, LKBuffers B, int n, LKParams P)
+__global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : 2)) void k_lk_fast(Pyramid PI, Pyramid PJ, LKBuffers B, int n, LKParams P)
 {
     using C = Cfg<WW, WH>;
     __shared__ uint32_t lds[C::LDS_DW];

@@ -52,6 +52,32 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Exact 64-lane sum when G-lane partial sums are known to fit int32 (G = 8 or 16): prefix sums inside
+// G-lane groups by DPP, then the 64/G group totals are read back as scalars and added in 64 bits on the
+// scalar unit.  Needs |v| * G < 2^31.
+template <int G>
+__device__ __forceinline__ long long wave_sum_grouped(int v)
+{
+    static_assert(G == 8 || G == 16, "group size");
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    if (G == 16) v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    long long t = 0;
+#pragma unroll
+    for (int g = 0; g < 64 / G; g++) t += (long long)__builtin_amdgcn_readlane(v, g * G + G - 1);
+    return t;
+}
+
+// correctly rounded int64 -> float for |t| < 2^52, through one exact double
+__device__ __forceinline__ float i64_to_float(long long t)
+{
+    const double d = (double)(int)(t >> 32) * 4294967296.0 + (double)(unsigned)t;
+    return (float)d;
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // Exact sum of per-lane int32 partials as int64: the partial is split into a 16-bit low part and a
 // signed high part so that neither 64-lane sum can overflow 32 bits.
 __device__ __forceinline__ long long wave_sum_exact(int v)
@@ -59,6 +85,13 @@ __device__ __forceinline__ long long wave_sum_exact(int v)
     const int lo = wave_sum_i32(v & 0xffff);
     const int hi = wave_sum_i32(v >> 16);
     return ((long long)hi << 16) + (long long)lo;
+}
+
+template <bool SMALL, int G>
+__device__ __forceinline__ long long sum_pick(int v)
+{
+    if constexpr (SMALL) return wave_sum_grouped<G>(v);
+    else return wave_sum_exact(v);
 }
 
 }  // namespace lk
