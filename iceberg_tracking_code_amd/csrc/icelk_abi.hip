@@ -22,6 +22,11 @@ struct Ctx {
     int device = 0;
     int max_w = 0, max_h = 0, n_slots = 0, max_pts = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
+    // Detection (corner candidates, min-distance, sort) runs on its own stream: it only needs the frame,
+    // not the tracker's results, so it overlaps the LK launch of the same frame (s1:323-326 vs s1:437).
+    hipStream_t det_stream = nullptr;
+    hipEvent_t det_done = nullptr;      // corners of the latest detection are in d_corners
+    hipEvent_t corners_free = nullptr;  // the compute stream has consumed d_corners
     std::vector<Slot> slots;
     std::string err;
 
@@ -93,20 +98,21 @@ static int check_launch(Ctx* c, const char* what)
 struct ProfScope {
     Ctx* c;
     int id;
+    hipStream_t st;
     ProfEvt ev{};
-    ProfScope(Ctx* c_, int id_) : c(c_), id(id_)
+    ProfScope(Ctx* c_, int id_, hipStream_t st_ = nullptr) : c(c_), id(id_), st(st_ ? st_ : c_->stream)
     {
         if (c->prof) {
             hipEventCreate(&ev.a);
             hipEventCreate(&ev.b);
             ev.id = id;
-            hipEventRecord(ev.a, c->stream);
+            hipEventRecord(ev.a, st);
         }
     }
     ~ProfScope()
     {
         if (c->prof) {
-            hipEventRecord(ev.b, c->stream);
+            hipEventRecord(ev.b, st);
             c->evts.push_back(ev);
         }
     }
@@ -269,7 +275,12 @@ static void destroy_ctx(Ctx* c)
     for (auto& s : c->slots) {
         if (s.base) hipFree(s.base);
         if (s.ready) hipEventDestroy(s.ready);
+        if (s.frame_ev) hipEventDestroy(s.frame_ev);
     }
+    if (c->det_stream) hipStreamSynchronize(c->det_stream);
+    if (c->det_done) hipEventDestroy(c->det_done);
+    if (c->corners_free) hipEventDestroy(c->corners_free);
+    if (c->det_stream) hipStreamDestroy(c->det_stream);
     void* ptrs[] = {c->d_bgr, c->d_mask, c->d_p0, c->d_p1, c->d_p0r, c->d_err_f, c->d_err_b, c->d_dist, c->d_corners,
                     c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.max_key, c->D.cand, c->D.cand_count,
                     c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.cell_cand, c->D.state, c->D.undecided,
@@ -292,9 +303,13 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
     if (rc) return rc;
     if (!(quality > 0) || min_distance < 0 || block_size <= 0) FAIL(c, ICELK_EARG, "bad detector parameters");
     if (min_eig_lds_bytes(block_size) > 150 * 1024) FAIL(c, ICELK_EARG, "blockSize too large");
-    rc = wait_slot(c, slot);
-    if (rc) return rc;
     Slot& s = c->slots[slot];
+    const hipStream_t ds = c->det_stream;
+    // the frame must be in the slot (ingest on the compute or the copy stream) and the previous corner list
+    // must have been consumed before this detection overwrites it; nothing else orders the two streams
+    HIPCHK(c, hipStreamWaitEvent(ds, s.frame_ev, 0));
+    if (s.pending) HIPCHK(c, hipStreamWaitEvent(ds, s.ready, 0));
+    HIPCHK(c, hipStreamWaitEvent(ds, c->corners_free, 0));
     const int w = s.w, h = s.h;
     const uint8_t* mask = nullptr;
     if (use_mask) {
@@ -312,9 +327,9 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
         if (ncell_all + 1 > c->ncell_cap) FAIL(c, ICELK_ECAP, "cell grid larger than allocated");
     }
     {
-        ProfScope p(c, K_EIG);
-        launch_detect_reset(c->stream, D, (int)ncell_all);
-        launch_candidates(c->stream, D, s.lv[0], block_size, mask, c->mask_pitch, quality, generic, nullptr);
+        ProfScope p(c, K_EIG, ds);
+        launch_detect_reset(ds, D, (int)ncell_all);
+        launch_candidates(ds, D, s.lv[0], block_size, mask, c->mask_pitch, quality, generic, nullptr);
     }
     rc = check_launch(c, "corner candidates");
     if (rc) return rc;
@@ -322,11 +337,11 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
     int counts[3] = {0, 0, 0};
     const int* cand_count_ptr = D.cand_count;
     auto fetch = [&]() -> int {
-        HIPCHK(c, hipMemcpyAsync(&counts[0], cand_count_ptr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&counts[1], D.acc_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&counts[0], cand_count_ptr, sizeof(int), hipMemcpyDeviceToHost, ds));
+        HIPCHK(c, hipMemcpyAsync(&counts[1], D.acc_count, sizeof(int), hipMemcpyDeviceToHost, ds));
         HIPCHK(c, hipMemcpyAsync(&counts[2], D.undecided + suppress_launch_count() - 1, sizeof(int),
-                                 hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+                                 hipMemcpyDeviceToHost, ds));
+        HIPCHK(c, hipStreamSynchronize(ds));
         return ICELK_OK;
     };
     const unsigned long long* sorted = nullptr;
@@ -337,31 +352,31 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
         if (ncell + 1 > c->ncell_cap) FAIL(c, ICELK_ECAP, "cell grid larger than allocated");
         cand_count_ptr = D.cell_start + ncell;
         {
-            ProfScope p(c, K_SUPPRESS);
-            launch_min_distance(c->stream, D, w, h, min_distance, quality);
+            ProfScope p(c, K_SUPPRESS, ds);
+            launch_min_distance(ds, D, w, h, min_distance, quality);
         }
         rc = check_launch(c, "min_distance");
         if (rc) return rc;
         if ((rc = fetch())) return rc;
         for (int guard = 0; counts[2] != 0; guard++) {
             if (guard > 100000) FAIL(c, ICELK_EHIP, "min-distance suppression did not converge");
-            continue_min_distance(c->stream, D, w, h, min_distance);
+            continue_min_distance(ds, D, w, h, min_distance);
             if ((rc = fetch())) return rc;
         }
         total = counts[1];
         c->last_candidates = counts[0];
         c->last_accepted = total;
         if (total == 0) return ICELK_OK;
-        sort_keys_desc(c->stream, D, D.acc, D.acc_sorted, total);
+        sort_keys_desc(ds, D, D.acc, D.acc_sorted, total);
         sorted = D.acc_sorted;
     } else {
-        launch_flatten(c->stream, D, quality);
+        launch_flatten(ds, D, quality);
         if ((rc = fetch())) return rc;
         total = counts[0];
         c->last_candidates = total;
         c->last_accepted = total;
         if (total == 0) return ICELK_OK;
-        sort_keys_desc(c->stream, D, D.cand, D.cell_cand, total);
+        sort_keys_desc(ds, D, D.cand, D.cell_cand, total);
         sorted = D.cell_cand;
     }
     rc = check_launch(c, "sort");
@@ -370,11 +385,12 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
     if (max_corners > 0 && n > max_corners) n = max_corners;
     if (n > cap || n > c->max_pts) FAIL(c, ICELK_ECAP, "more corners than the output capacity (raise max_pts)");
     {
-        ProfScope p(c, K_EMIT);
-        launch_emit_corners(c->stream, sorted, n, w, c->d_corners);
+        ProfScope p(c, K_EMIT, ds);
+        launch_emit_corners(ds, sorted, n, w, c->d_corners);
     }
     rc = check_launch(c, "emit");
     if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->det_done, ds));
     *n_out = n;
     return ICELK_OK;
 }
@@ -482,7 +498,10 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         return code;
     };
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->det_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->det_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->corners_free, hipEventDisableTiming) != hipSuccess) {
         c->err = "hipStreamCreate failed";
         return fail(ICELK_EHIP);
     }
@@ -492,7 +511,8 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
     for (auto& s : c->slots) {
         if ((rc = dmalloc(c, &s.base, sb))) return fail(rc);
         s.bytes = sb;
-        if (hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess) {
+        if (hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.frame_ev, hipEventDisableTiming) != hipSuccess) {
             c->err = "hipEventCreate failed";
             return fail(ICELK_EHIP);
         }
@@ -552,6 +572,7 @@ int icelk_sync(icelk_t* h)
     if (!h) return ICELK_EARG;
     Ctx* c = C(h);
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->det_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ICELK_OK;
 }
@@ -568,6 +589,7 @@ int icelk_upload_gray(icelk_t* h, int slot, const uint8_t* host, int w, int h_, 
     Slot& s = c->slots[slot];
     HIPCHK(c, hipMemcpy2DAsync(s.lv[0].ptr, s.lv[0].pitch, host, stride, w, h_, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventRecord(s.frame_ev, c->stream));
     s.levels_built = 1;
     s.pending = false;
     return ICELK_OK;
@@ -588,6 +610,7 @@ int icelk_upload_gray_async(icelk_t* h, int slot, const uint8_t* pinned_host, in
     HIPCHK(c, hipMemcpy2DAsync(s.lv[0].ptr, s.lv[0].pitch, pinned_host, stride, w, h_, hipMemcpyHostToDevice,
                                c->copy_stream));
     HIPCHK(c, hipEventRecord(s.ready, c->copy_stream));
+    HIPCHK(c, hipEventRecord(s.frame_ev, c->copy_stream));
     s.pending = true;
     s.levels_built = 1;
     return ICELK_OK;
@@ -619,6 +642,7 @@ int icelk_upload_bgr(icelk_t* h, int slot, const uint8_t* host, int w, int h_, i
     rc = check_launch(c, "bgr2gray");
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventRecord(s.frame_ev, c->stream));
     s.levels_built = 1;
     s.pending = false;
     return ICELK_OK;
@@ -634,6 +658,7 @@ int icelk_set_gray_device(icelk_t* h, int slot, const void* dev, int w, int h_, 
     if (rc) return rc;
     Slot& s = c->slots[slot];
     HIPCHK(c, hipMemcpy2DAsync(s.lv[0].ptr, s.lv[0].pitch, dev, stride, w, h_, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(s.frame_ev, c->stream));
     s.levels_built = 1;
     s.pending = false;
     return ICELK_OK;
@@ -656,6 +681,7 @@ int icelk_cvt_bgr_device(icelk_t* h, int slot, const void* dev_bgr, int w, int h
     }
     rc = check_launch(c, "bgr2gray");
     if (rc) return rc;
+    HIPCHK(c, hipEventRecord(s.frame_ev, c->stream));
     s.levels_built = 1;
     s.pending = false;
     return ICELK_OK;
@@ -675,6 +701,7 @@ int icelk_synth_frame(icelk_t* h, int slot, int w, int h_, int64_t ux, int64_t u
     }
     rc = check_launch(c, "synth");
     if (rc) return rc;
+    HIPCHK(c, hipEventRecord(s.frame_ev, c->stream));
     s.levels_built = 1;
     s.pending = false;
     return ICELK_OK;
@@ -844,6 +871,7 @@ int icelk_set_mask(icelk_t* h, const uint8_t* host_mask, int w, int h_, int stri
     }
     if (w <= 0 || h_ <= 0 || stride < w) FAIL(c, ICELK_EARG, "bad mask");
     if (w > c->max_w || h_ > c->max_h) FAIL(c, ICELK_ECAP, "mask larger than max_w x max_h");
+    HIPCHK(c, hipStreamSynchronize(c->det_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy2DAsync(c->d_mask, c->mask_pitch, host_mask, stride, w, h_, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -865,6 +893,8 @@ int icelk_min_eig_map(icelk_t* h, int slot, int block_size, float* host_out, int
     if (min_eig_lds_bytes(block_size) > 150 * 1024) FAIL(c, ICELK_EARG, "blockSize too large");
     rc = wait_slot(c, slot);
     if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));       // the frame is in place
+    HIPCHK(c, hipStreamSynchronize(c->det_stream));   // the detector scratch is free
     {
         ProfScope p(c, K_EIG);
         launch_detect_reset(c->stream, c->D, 0);
@@ -893,8 +923,8 @@ int icelk_good_features(icelk_t* h, int slot, int use_mask, int max_corners, dou
     int rc = detect_core(c, slot, use_mask, max_corners, quality_level, min_distance, block_size, cap, &n);
     if (rc) return rc;
     if (n > 0) {
-        HIPCHK(c, hipMemcpyAsync(out_xy, c->d_corners, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpyAsync(out_xy, c->d_corners, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->det_stream));
+        HIPCHK(c, hipStreamSynchronize(c->det_stream));
     }
     *out_n = n;
     return ICELK_OK;
@@ -919,10 +949,12 @@ int icelk_seg_detect(icelk_t* h, int slot, int use_mask, int max_corners, double
     int n = 0;
     int rc = detect_core(c, slot, use_mask, max_corners, quality_level, min_distance, block_size, c->max_pts, &n);
     if (rc) return rc;
+    if (n > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->det_done, 0));
     launch_seg_init(c->stream, c->d_corners, n, c->d_live[0], c->d_origin[0], c->d_tracks, kMaxVert, c->d_nlive,
                     c->d_tracked);
     rc = check_launch(c, "seg_init");
     if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->corners_free, c->stream));
     c->seg_cur = 0;
     c->seg_vert = 1;
     c->seg_upper = n;

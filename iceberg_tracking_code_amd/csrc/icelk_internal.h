@@ -58,6 +58,7 @@ struct Slot {
     Level lv[kMaxLevels];
     hipEvent_t ready = nullptr;   // upload-complete event (async uploads)
     bool pending = false;
+    hipEvent_t frame_ev = nullptr;  // level 0 written (recorded on the compute stream by every ingest call)
 };
 
 struct ProfEvt {
