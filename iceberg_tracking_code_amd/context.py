@@ -192,6 +192,15 @@ class Context:
                                             float(minDistance), int(blockSize), C.byref(n)))
         return n.value
 
+    def seg_detect_begin(self, slot, qualityLevel, minDistance, use_mask=False, blockSize=3):
+        self._ck(self._lib.icelk_seg_detect_begin(self._h, slot, 1 if use_mask else 0, float(qualityLevel),
+                                                  float(minDistance), int(blockSize)))
+
+    def seg_detect_finish(self, maxCorners):
+        n = C.c_int(0)
+        self._ck(self._lib.icelk_seg_detect_finish(self._h, int(maxCorners), C.byref(n)))
+        return n.value
+
     def seg_track(self, slot_prev, slot_next, winSize=(21, 21), maxLevel=3, criteria=DEFAULT_CRITERIA,
                   minEigThreshold=1e-4, fb_threshold=1.0, wait=True):
         t, cnt, eps = _criteria(criteria)

@@ -18,6 +18,14 @@ static const char* kKernelNames[K_COUNT_] = {
     "compact", "synth",
 };
 
+struct DetectJob {
+    bool active = false;
+    int w = 0, h = 0;
+    double quality = 0, min_distance = 0;
+    size_t ncell = 0;
+    const int* cand_count_ptr = nullptr;
+};
+
 struct Ctx {
     int device = 0;
     int max_w = 0, max_h = 0, n_slots = 0, max_pts = 0;
@@ -57,6 +65,8 @@ struct Ctx {
     bool seg_active = false;
 
     int last_candidates = 0, last_accepted = 0;   // of the latest detection
+    DetectJob job{};
+    int* h_counts = nullptr;   // pinned, device-visible: {candidates, accepted, undecided} of the job
 
     // profiling
     bool prof = false;
@@ -266,6 +276,16 @@ static int dmalloc(Ctx* c, T** p, size_t count)
     return ICELK_OK;
 }
 
+// the detection chain is ~20 short kernels; a high-priority queue keeps each of them from waiting behind
+// the thousands of pending workgroups of the tracker launch it overlaps with
+static hipError_t create_priority_stream(hipStream_t* s)
+{
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+}
+
 static void destroy_ctx(Ctx* c)
 {
     if (!c) return;
@@ -281,6 +301,7 @@ static void destroy_ctx(Ctx* c)
     if (c->det_done) hipEventDestroy(c->det_done);
     if (c->corners_free) hipEventDestroy(c->corners_free);
     if (c->det_stream) hipStreamDestroy(c->det_stream);
+    if (c->h_counts) hipHostFree(c->h_counts);
     void* ptrs[] = {c->d_bgr, c->d_mask, c->d_p0, c->d_p1, c->d_p0r, c->d_err_f, c->d_err_b, c->d_dist, c->d_corners,
                     c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.max_key, c->D.cand, c->D.cand_count,
                     c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.cell_cand, c->D.state, c->D.undecided,
@@ -295,21 +316,36 @@ static void destroy_ctx(Ctx* c)
 }
 
 // ---- detector core shared by icelk_good_features and icelk_seg_detect --------------------------
-// On success the first *n_out corners are in c->d_corners (device), in response order.
-static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double quality, double min_distance,
-                       int block_size, int cap, int* n_out)
+// detect_begin enqueues K6..K8 on the detection stream and returns at once; detect_finish waits for the
+// counts, sorts the accepted corners and leaves the first *n_out of them in c->d_corners (device), in
+// response order.
+__global__ void k_publish_counts(const int* __restrict__ cand, const int* __restrict__ acc,
+                                 const int* __restrict__ undecided, int* __restrict__ host_out)
+{
+    host_out[0] = *cand;
+    host_out[1] = *acc;
+    host_out[2] = *undecided;
+    __threadfence_system();
+}
+
+static int fetch_counts(Ctx* c)
+{
+    const DetectJob& J = c->job;
+    hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(1), 0, c->det_stream, J.cand_count_ptr, c->D.acc_count,
+                       c->D.undecided + suppress_launch_count() - 1, c->h_counts);
+    HIPCHK(c, hipStreamSynchronize(c->det_stream));
+    return ICELK_OK;
+}
+
+static int detect_begin(Ctx* c, int slot, int use_mask, double quality, double min_distance, int block_size)
 {
     int rc = check_slot(c, slot, true);
     if (rc) return rc;
     if (!(quality > 0) || min_distance < 0 || block_size <= 0) FAIL(c, ICELK_EARG, "bad detector parameters");
     if (min_eig_lds_bytes(block_size) > 150 * 1024) FAIL(c, ICELK_EARG, "blockSize too large");
+    if (c->job.active) FAIL(c, ICELK_ESTATE, "a detection is already in flight");
     Slot& s = c->slots[slot];
     const hipStream_t ds = c->det_stream;
-    // the frame must be in the slot (ingest on the compute or the copy stream) and the previous corner list
-    // must have been consumed before this detection overwrites it; nothing else orders the two streams
-    HIPCHK(c, hipStreamWaitEvent(ds, s.frame_ev, 0));
-    if (s.pending) HIPCHK(c, hipStreamWaitEvent(ds, s.ready, 0));
-    HIPCHK(c, hipStreamWaitEvent(ds, c->corners_free, 0));
     const int w = s.w, h = s.h;
     const uint8_t* mask = nullptr;
     if (use_mask) {
@@ -318,61 +354,71 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
         mask = c->d_mask;
     }
     DetectScratch& D = c->D;
-    *n_out = 0;
-    const bool generic = getenv("ICELK_GENERIC_CORNERS") != nullptr;
-    size_t ncell_all = 0;
+    size_t ncell = 0;
     if (min_distance >= 1) {
-        const int cell0 = (int)lrint(min_distance);
-        ncell_all = (size_t)((w + cell0 - 1) / cell0) * ((h + cell0 - 1) / cell0);
-        if (ncell_all + 1 > c->ncell_cap) FAIL(c, ICELK_ECAP, "cell grid larger than allocated");
+        const int cell = (int)lrint(min_distance);
+        ncell = (size_t)((w + cell - 1) / cell) * ((h + cell - 1) / cell);
+        if (ncell + 1 > c->ncell_cap) FAIL(c, ICELK_ECAP, "cell grid larger than allocated");
     }
+    // the frame must be in the slot (ingest on the compute or the copy stream) and the previous corner list
+    // must have been consumed before this detection overwrites it; nothing else orders the two streams
+    HIPCHK(c, hipStreamWaitEvent(ds, s.frame_ev, 0));
+    if (s.pending) HIPCHK(c, hipStreamWaitEvent(ds, s.ready, 0));
+    HIPCHK(c, hipStreamWaitEvent(ds, c->corners_free, 0));
+    const bool generic = getenv("ICELK_GENERIC_CORNERS") != nullptr;
     {
         ProfScope p(c, K_EIG, ds);
-        launch_detect_reset(ds, D, (int)ncell_all);
+        launch_detect_reset(ds, D, (int)ncell);
         launch_candidates(ds, D, s.lv[0], block_size, mask, c->mask_pitch, quality, generic, nullptr);
     }
     rc = check_launch(c, "corner candidates");
     if (rc) return rc;
-    // one host round trip per detection: {candidates, accepted, undecided}
-    int counts[3] = {0, 0, 0};
-    const int* cand_count_ptr = D.cand_count;
-    auto fetch = [&]() -> int {
-        HIPCHK(c, hipMemcpyAsync(&counts[0], cand_count_ptr, sizeof(int), hipMemcpyDeviceToHost, ds));
-        HIPCHK(c, hipMemcpyAsync(&counts[1], D.acc_count, sizeof(int), hipMemcpyDeviceToHost, ds));
-        HIPCHK(c, hipMemcpyAsync(&counts[2], D.undecided + suppress_launch_count() - 1, sizeof(int),
-                                 hipMemcpyDeviceToHost, ds));
-        HIPCHK(c, hipStreamSynchronize(ds));
-        return ICELK_OK;
-    };
+    DetectJob& J = c->job;
+    J.w = w;
+    J.h = h;
+    J.quality = quality;
+    J.min_distance = min_distance;
+    J.ncell = ncell;
+    if (min_distance >= 1) {
+        J.cand_count_ptr = D.cell_start + ncell;
+        ProfScope p(c, K_SUPPRESS, ds);
+        launch_min_distance(ds, D, w, h, min_distance, quality);
+    } else {
+        J.cand_count_ptr = D.cand_count;
+        launch_flatten(ds, D, quality);
+    }
+    rc = check_launch(c, "min_distance");
+    if (rc) return rc;
+    J.active = true;
+    return ICELK_OK;
+}
+
+static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
+{
+    DetectJob& J = c->job;
+    if (!J.active) FAIL(c, ICELK_ESTATE, "no detection in flight");
+    J.active = false;
+    *n_out = 0;
+    const hipStream_t ds = c->det_stream;
+    DetectScratch& D = c->D;
+    int rc = fetch_counts(c);   // the one host round trip of a detection: {candidates, accepted, undecided}
+    if (rc) return rc;
     const unsigned long long* sorted = nullptr;
     int total = 0;
-    if (min_distance >= 1) {
-        const int cell = (int)lrint(min_distance);
-        const size_t ncell = (size_t)((w + cell - 1) / cell) * ((h + cell - 1) / cell);
-        if (ncell + 1 > c->ncell_cap) FAIL(c, ICELK_ECAP, "cell grid larger than allocated");
-        cand_count_ptr = D.cell_start + ncell;
-        {
-            ProfScope p(c, K_SUPPRESS, ds);
-            launch_min_distance(ds, D, w, h, min_distance, quality);
-        }
-        rc = check_launch(c, "min_distance");
-        if (rc) return rc;
-        if ((rc = fetch())) return rc;
-        for (int guard = 0; counts[2] != 0; guard++) {
+    if (J.min_distance >= 1) {
+        for (int guard = 0; c->h_counts[2] != 0; guard++) {
             if (guard > 100000) FAIL(c, ICELK_EHIP, "min-distance suppression did not converge");
-            continue_min_distance(ds, D, w, h, min_distance);
-            if ((rc = fetch())) return rc;
+            continue_min_distance(ds, D, J.w, J.h, J.min_distance);
+            if ((rc = fetch_counts(c))) return rc;
         }
-        total = counts[1];
-        c->last_candidates = counts[0];
+        total = c->h_counts[1];
+        c->last_candidates = c->h_counts[0];
         c->last_accepted = total;
         if (total == 0) return ICELK_OK;
         sort_keys_desc(ds, D, D.acc, D.acc_sorted, total);
         sorted = D.acc_sorted;
     } else {
-        launch_flatten(ds, D, quality);
-        if ((rc = fetch())) return rc;
-        total = counts[0];
+        total = c->h_counts[0];
         c->last_candidates = total;
         c->last_accepted = total;
         if (total == 0) return ICELK_OK;
@@ -386,13 +432,22 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
     if (n > cap || n > c->max_pts) FAIL(c, ICELK_ECAP, "more corners than the output capacity (raise max_pts)");
     {
         ProfScope p(c, K_EMIT, ds);
-        launch_emit_corners(ds, sorted, n, w, c->d_corners);
+        launch_emit_corners(ds, sorted, n, J.w, c->d_corners);
     }
     rc = check_launch(c, "emit");
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->det_done, ds));
     *n_out = n;
     return ICELK_OK;
+}
+
+static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double quality, double min_distance,
+                       int block_size, int cap, int* n_out)
+{
+    *n_out = 0;
+    int rc = detect_begin(c, slot, use_mask, quality, min_distance, block_size);
+    if (rc) return rc;
+    return detect_finish(c, max_corners, cap, n_out);
 }
 
 // shared by icelk_seg_track / icelk_seg_track_async
@@ -499,7 +554,8 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
     };
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->det_stream, hipStreamNonBlocking) != hipSuccess ||
+        create_priority_stream(&c->det_stream) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), 64, hipHostMallocMapped) != hipSuccess ||
         hipEventCreateWithFlags(&c->det_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->corners_free, hipEventDisableTiming) != hipSuccess) {
         c->err = "hipStreamCreate failed";
@@ -940,14 +996,22 @@ int icelk_detect_stats(icelk_t* h, int* n_candidates, int* n_accepted)
 }
 
 // ---- segment state -----------------------------------------------------------------------------
-int icelk_seg_detect(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level, double min_distance,
-                     int block_size, int* out_n)
+int icelk_seg_detect_begin(icelk_t* h, int slot, int use_mask, double quality_level, double min_distance,
+                            int block_size)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    return detect_begin(c, slot, use_mask, quality_level, min_distance, block_size);
+}
+
+int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n)
 {
     if (!h) return ICELK_EARG;
     Ctx* c = C(h);
     HIPCHK(c, hipSetDevice(c->device));
     int n = 0;
-    int rc = detect_core(c, slot, use_mask, max_corners, quality_level, min_distance, block_size, c->max_pts, &n);
+    int rc = detect_finish(c, max_corners, c->max_pts, &n);
     if (rc) return rc;
     if (n > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->det_done, 0));
     launch_seg_init(c->stream, c->d_corners, n, c->d_live[0], c->d_origin[0], c->d_tracks, kMaxVert, c->d_nlive,
@@ -961,6 +1025,14 @@ int icelk_seg_detect(icelk_t* h, int slot, int use_mask, int max_corners, double
     c->seg_active = true;
     if (out_n) *out_n = n;
     return ICELK_OK;
+}
+
+int icelk_seg_detect(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level, double min_distance,
+                     int block_size, int* out_n)
+{
+    int rc = icelk_seg_detect_begin(h, slot, use_mask, quality_level, min_distance, block_size);
+    if (rc) return rc;
+    return icelk_seg_detect_finish(h, max_corners, out_n);
 }
 
 int icelk_seg_track_async(icelk_t* h, int slot_prev, int slot_next, int win_w, int win_h, int max_level, int crit_type,

@@ -209,15 +209,20 @@ class SegmentTracker:
     def _step(self, slot, wait):
         out = None
         prev = self.cur
+        detect = self.counter % self.track_len == 0
+        if detect:
+            # the detector needs this frame only: start it first, on its own stream, so that it runs beside
+            # the tracker launch below (the reference does them back to back, s1:323-326 then s1:437)
+            self.ctx.seg_detect_begin(slot, self.fp["qualityLevel"], self.fp["minDistance"], self.use_mask,
+                                      self.fp.get("blockSize", 3))
         if self.active:
             self.ctx.seg_track(prev, slot, self.lk["winSize"], self.lk["maxLevel"], self.lk["criteria"],
                                self.lk.get("minEigThreshold", 1e-4), self.fb_threshold, wait=False)
-        if self.counter % self.track_len == 0:
+        if detect:
             if self.counter > 0 and wait:
                 tracks, quality = self.ctx.seg_read()
                 out = (self.seg_first, tracks, quality)
-            self.n_detected = self.ctx.seg_detect(slot, self.fp["maxCorners"], self.fp["qualityLevel"],
-                                                  self.fp["minDistance"], self.use_mask, self.fp.get("blockSize", 3))
+            self.n_detected = self.ctx.seg_detect_finish(self.fp["maxCorners"])
             self.active = True
             self.seg_first = self.counter
         self.cur = slot
