@@ -24,6 +24,7 @@ struct DetectJob {
     double quality = 0, min_distance = 0;
     size_t ncell = 0;
     const int* cand_count_ptr = nullptr;
+    int prune_want = 0;   // > 0: top-K pruning is on for this job
 };
 
 struct Ctx {
@@ -66,6 +67,8 @@ struct Ctx {
 
     int last_candidates = 0, last_accepted = 0;   // of the latest detection
     DetectJob job{};
+    size_t reset_ncell = 0;    // the detector counters are known to be zero for grids up to this many cells
+    bool counters_clean = false;
     int* h_counts = nullptr;   // pinned, device-visible: {candidates, accepted, undecided} of the job
 
     // profiling
@@ -305,7 +308,7 @@ static void destroy_ctx(Ctx* c)
     void* ptrs[] = {c->d_bgr, c->d_mask, c->d_p0, c->d_p1, c->d_p0r, c->d_err_f, c->d_err_b, c->d_dist, c->d_corners,
                     c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.max_key, c->D.cand, c->D.cand_count,
                     c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.cell_cand, c->D.state, c->D.undecided,
-                    c->D.acc, c->D.acc_sorted, c->D.acc_count, c->D.blk_count, c->D.sort_tmp, c->d_live[0], c->d_live[1],
+                    c->D.acc, c->D.acc_sorted, c->D.acc_count, c->D.blk_count, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->d_live[0], c->d_live[1],
                     c->d_origin[0], c->d_origin[1], c->d_nlive, c->d_tracked, c->d_tracks, c->d_quality,
                     c->d_out_tracks, c->d_out_quality};
     for (void* p : ptrs)
@@ -320,11 +323,13 @@ static void destroy_ctx(Ctx* c)
 // counts, sorts the accepted corners and leaves the first *n_out of them in c->d_corners (device), in
 // response order.
 __global__ void k_publish_counts(const int* __restrict__ cand, const int* __restrict__ acc,
-                                 const int* __restrict__ undecided, int* __restrict__ host_out)
+                                 const int* __restrict__ undecided, const unsigned* __restrict__ prune_key,
+                                 int* __restrict__ host_out)
 {
     host_out[0] = *cand;
     host_out[1] = *acc;
     host_out[2] = *undecided;
+    host_out[3] = (int)(*prune_key != 0u);
     __threadfence_system();
 }
 
@@ -332,12 +337,13 @@ static int fetch_counts(Ctx* c)
 {
     const DetectJob& J = c->job;
     hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(1), 0, c->det_stream, J.cand_count_ptr, c->D.acc_count,
-                       c->D.undecided + suppress_launch_count() - 1, c->h_counts);
+                       c->D.undecided + suppress_launch_count() - 1, c->D.prune_key, c->h_counts);
     HIPCHK(c, hipStreamSynchronize(c->det_stream));
     return ICELK_OK;
 }
 
-static int detect_begin(Ctx* c, int slot, int use_mask, double quality, double min_distance, int block_size)
+static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double quality, double min_distance,
+                        int block_size)
 {
     int rc = check_slot(c, slot, true);
     if (rc) return rc;
@@ -368,7 +374,10 @@ static int detect_begin(Ctx* c, int slot, int use_mask, double quality, double m
     const bool generic = getenv("ICELK_GENERIC_CORNERS") != nullptr;
     {
         ProfScope p(c, K_EIG, ds);
-        launch_detect_reset(ds, D, (int)ncell);
+        // counters are normally left zeroed by the previous detection (the reset runs after its last kernel,
+        // off the critical path); reset here only the first time or when the cell grid grew
+        if (!c->counters_clean || ncell > c->reset_ncell) launch_detect_reset(ds, D, (int)ncell, true);
+        c->counters_clean = false;
         launch_candidates(ds, D, s.lv[0], block_size, mask, c->mask_pitch, quality, generic, nullptr);
     }
     rc = check_launch(c, "corner candidates");
@@ -379,10 +388,15 @@ static int detect_begin(Ctx* c, int slot, int use_mask, double quality, double m
     J.quality = quality;
     J.min_distance = min_distance;
     J.ncell = ncell;
+    // top-K pruning (k_corners.hip): worthwhile when maxCorners is a real cap; 8x leaves a wide margin over the
+    // ~1 in 4 candidates that survive the minDistance rule, and detect_finish verifies it
+    J.prune_want = 0;
+    if (min_distance >= 1 && max_corners > 0 && max_corners <= (1 << 24) && !getenv("ICELK_NO_PRUNE"))
+        J.prune_want = 8 * max_corners;
     if (min_distance >= 1) {
         J.cand_count_ptr = D.cell_start + ncell;
         ProfScope p(c, K_SUPPRESS, ds);
-        launch_min_distance(ds, D, w, h, min_distance, quality);
+        launch_min_distance(ds, D, w, h, min_distance, quality, J.prune_want);
     } else {
         J.cand_count_ptr = D.cand_count;
         launch_flatten(ds, D, quality);
@@ -406,10 +420,23 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
     const unsigned long long* sorted = nullptr;
     int total = 0;
     if (J.min_distance >= 1) {
-        for (int guard = 0; c->h_counts[2] != 0; guard++) {
-            if (guard > 100000) FAIL(c, ICELK_EHIP, "min-distance suppression did not converge");
-            continue_min_distance(ds, D, J.w, J.h, J.min_distance);
+        auto converge = [&]() -> int {
+            for (int guard = 0; c->h_counts[2] != 0; guard++) {
+                if (guard > 100000) FAIL(c, ICELK_EHIP, "min-distance suppression did not converge");
+                continue_min_distance(ds, D, J.w, J.h, J.min_distance);
+                int r = fetch_counts(c);
+                if (r) return r;
+            }
+            return ICELK_OK;
+        };
+        if ((rc = converge())) return rc;
+        if (J.prune_want > 0 && c->h_counts[3] && (max_corners <= 0 || c->h_counts[1] < max_corners)) {
+            // the pruned candidate set did not yield maxCorners corners: redo the stage on all candidates
+            launch_detect_reset(ds, D, (int)J.ncell, false);
+            launch_min_distance(ds, D, J.w, J.h, J.min_distance, J.quality, 0);
+            if ((rc = check_launch(c, "min_distance (unpruned)"))) return rc;
             if ((rc = fetch_counts(c))) return rc;
+            if ((rc = converge())) return rc;
         }
         total = c->h_counts[1];
         c->last_candidates = c->h_counts[0];
@@ -437,6 +464,9 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
     rc = check_launch(c, "emit");
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->det_done, ds));
+    launch_detect_reset(ds, D, (int)J.ncell, true);   // for the next detection
+    c->reset_ncell = J.ncell;
+    c->counters_clean = true;
     *n_out = n;
     return ICELK_OK;
 }
@@ -445,7 +475,7 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
                        int block_size, int cap, int* n_out)
 {
     *n_out = 0;
-    int rc = detect_begin(c, slot, use_mask, quality, min_distance, block_size);
+    int rc = detect_begin(c, slot, use_mask, max_corners, quality, min_distance, block_size);
     if (rc) return rc;
     return detect_finish(c, max_corners, cap, n_out);
 }
@@ -591,7 +621,8 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &D.cell_fill, c->ncell_cap)) || (rc = dmalloc(c, &D.cell_cand, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.state, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.undecided, 64)) ||
         (rc = dmalloc(c, &D.acc, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.acc_sorted, (size_t)D.cand_cap)) ||
-        (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, &D.blk_count, candidate_blocks(max_w, max_h) * 4)) || (rc = dmalloc(c, (uint8_t**)&D.sort_tmp, D.sort_tmp_bytes)) ||
+        (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, &D.blk_count, candidate_blocks(max_w, max_h) * 4)) ||
+        (rc = dmalloc(c, &D.key_hist, 1 << 16)) || (rc = dmalloc(c, &D.prune_key, 1)) || (rc = dmalloc(c, (uint8_t**)&D.sort_tmp, D.sort_tmp_bytes)) ||
         (rc = dmalloc(c, &c->d_live[0], 2 * np)) || (rc = dmalloc(c, &c->d_live[1], 2 * np)) ||
         (rc = dmalloc(c, &c->d_origin[0], np)) || (rc = dmalloc(c, &c->d_origin[1], np)) || (rc = dmalloc(c, &c->d_nlive, 2)) ||
         (rc = dmalloc(c, &c->d_tracked, 1)) || (rc = dmalloc(c, &c->d_tracks, np * kMaxVert * 2)) ||
@@ -953,7 +984,8 @@ int icelk_min_eig_map(icelk_t* h, int slot, int block_size, float* host_out, int
     HIPCHK(c, hipStreamSynchronize(c->det_stream));   // the detector scratch is free
     {
         ProfScope p(c, K_EIG);
-        launch_detect_reset(c->stream, c->D, 0);
+        launch_detect_reset(c->stream, c->D, 0, true);
+        c->counters_clean = false;
         if (fused_block_size(block_size) && !getenv("ICELK_GENERIC_CORNERS")) {
             launch_candidates(c->stream, c->D, s.lv[0], block_size, nullptr, 0, 1.0, false, c->D.eig);
         } else {
@@ -996,13 +1028,13 @@ int icelk_detect_stats(icelk_t* h, int* n_candidates, int* n_accepted)
 }
 
 // ---- segment state -----------------------------------------------------------------------------
-int icelk_seg_detect_begin(icelk_t* h, int slot, int use_mask, double quality_level, double min_distance,
-                            int block_size)
+int icelk_seg_detect_begin(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level,
+                            double min_distance, int block_size)
 {
     if (!h) return ICELK_EARG;
     Ctx* c = C(h);
     HIPCHK(c, hipSetDevice(c->device));
-    return detect_begin(c, slot, use_mask, quality_level, min_distance, block_size);
+    return detect_begin(c, slot, use_mask, max_corners, quality_level, min_distance, block_size);
 }
 
 int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n)
@@ -1030,7 +1062,7 @@ int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n)
 int icelk_seg_detect(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level, double min_distance,
                      int block_size, int* out_n)
 {
-    int rc = icelk_seg_detect_begin(h, slot, use_mask, quality_level, min_distance, block_size);
+    int rc = icelk_seg_detect_begin(h, slot, use_mask, max_corners, quality_level, min_distance, block_size);
     if (rc) return rc;
     return icelk_seg_detect_finish(h, max_corners, out_n);
 }

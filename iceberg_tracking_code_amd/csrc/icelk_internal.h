@@ -110,12 +110,14 @@ struct DetectScratch {
     void* sort_tmp;
     size_t sort_tmp_bytes;
     int* blk_count;        // candidates per producer workgroup (region layout, see k_corners.hip)
+    unsigned* key_hist;    // 65536 bins over the top 16 bits of the response key (top-K pruning)
+    unsigned* prune_key;   // 1: candidates with a smaller response key are ignored (0 = none)
     int src_nblk, src_region;   // geometry of the candidate regions of the detection in flight
 };
 void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig, const uint8_t* mask,
                     int mask_pitch, unsigned* max_key);
 bool fused_block_size(int bs);
-void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell);   // must precede launch_candidates
+void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, bool full);   // full: before launch_candidates
 // K6+K7: local maxima into per-workgroup regions of D.acc_sorted (stream order, no host sync)
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
                        int mask_pitch, double quality, bool use_generic, float* eig_out_or_null);
@@ -126,7 +128,9 @@ void launch_flatten(hipStream_t s, DetectScratch& D, double quality);
 // K8: regions -> D.acc / D.acc_count (unsorted accepted keys); candidates counted in D.cell_start[ncell];
 // D.undecided[suppress_launch_count()-1] != 0 afterwards means the relaxation has not converged yet: call
 // continue_min_distance and look again.
-void launch_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double min_distance, double quality);
+// prune_want > 0: only the ~prune_want strongest candidates take part (valid iff the accepted ones reach maxCorners)
+void launch_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double min_distance, double quality,
+                         int prune_want);
 void continue_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double min_distance);
 int suppress_launch_count();
 size_t sort_tmp_bytes(int n);

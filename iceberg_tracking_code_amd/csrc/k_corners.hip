@@ -423,17 +423,71 @@ __global__ __launch_bounds__(256) void k_nms_collect(const float* __restrict__ e
 // K8 helpers.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cell_count(CandSrc src, const unsigned* __restrict__ max_key, double quality,
-                                                    int w, int cell, int gw, int* __restrict__ cell_count)
+                                                    const unsigned* __restrict__ prune_key, int w, int cell, int gw,
+                                                    int* __restrict__ cell_count)
+{
+    const float thr = threshold_of(max_key, quality);
+    const unsigned pk = *prune_key;
+    for (int b = blockIdx.x; b < src.nblk; b += gridDim.x) {
+        const int cnt = src.blk_count[b];
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            const unsigned long long key = src.keys[(size_t)b * src.region + i];
+            if ((unsigned)(key >> 32) < pk || !(key_to_float((unsigned)(key >> 32)) > thr)) continue;
+            const unsigned idx = (unsigned)key;
+            const int y = (int)(idx >> 16), x = (int)(idx & 0xffffu);
+            atomicAdd(&cell_count[(y / cell) * gw + (x / cell)], 1);
+        }
+    }
+}
+
+// ---- top-K pruning when maxCorners caps the output ------------------------------------------------
+// Whether a candidate is accepted depends only on STRONGER candidates, so the accepted candidates among the K
+// strongest are exactly the greedy-accepted ones among them; if they number >= maxCorners, the weaker
+// candidates can never appear in the output and need not be binned, relaxed or sorted.  K is found from a
+// 65536-bin histogram of the response key (its top 16 bits); the host checks "accepted >= maxCorners" at its
+// one synchronisation point and reruns unpruned otherwise.
+constexpr int KEY_BINS = 1 << 16;
+__global__ __launch_bounds__(256) void k_key_hist(CandSrc src, const unsigned* __restrict__ max_key, double quality,
+                                                  unsigned* __restrict__ hist)
 {
     const float thr = threshold_of(max_key, quality);
     for (int b = blockIdx.x; b < src.nblk; b += gridDim.x) {
         const int cnt = src.blk_count[b];
         for (int i = threadIdx.x; i < cnt; i += 256) {
-            const unsigned long long key = src.keys[(size_t)b * src.region + i];
-            if (!(key_to_float((unsigned)(key >> 32)) > thr)) continue;
-            const unsigned idx = (unsigned)key;
-            const int y = (int)(idx >> 16), x = (int)(idx & 0xffffu);
-            atomicAdd(&cell_count[(y / cell) * gw + (x / cell)], 1);
+            const unsigned k = (unsigned)(src.keys[(size_t)b * src.region + i] >> 32);
+            if (key_to_float(k) > thr) atomicAdd(&hist[k >> 16], 1u);
+        }
+    }
+}
+
+// prune_key = lowest key of the highest bins that together hold >= want candidates (0 = keep everything)
+__global__ __launch_bounds__(1024) void k_key_select(const unsigned* __restrict__ hist, unsigned want,
+                                                     unsigned* __restrict__ prune_key)
+{
+    __shared__ unsigned part[1024];
+    const int tid = threadIdx.x;
+    constexpr int PER = KEY_BINS / 1024;
+    unsigned s = 0;
+    for (int i = 0; i < PER; i++) s += hist[tid * PER + i];
+    part[tid] = s;
+    __syncthreads();
+    // suffix sums over threads (thread 1023 owns the strongest bins)
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = tid + o < 1024 ? part[tid + o] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const unsigned above = tid + 1 < 1024 ? part[tid + 1] : 0u;   // candidates in stronger threads' bins
+    if (tid == 0 && part[0] < want) *prune_key = 0u;
+    if (above < want && part[tid] >= want) {
+        unsigned run = above;
+        for (int i = PER - 1; i >= 0; i--) {
+            run += hist[tid * PER + i];
+            if (run >= want) {
+                *prune_key = (unsigned)(tid * PER + i) << 16;
+                break;
+            }
         }
     }
 }
@@ -496,17 +550,18 @@ __global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ count, in
 }
 
 __global__ __launch_bounds__(256) void k_cell_fill(CandSrc src, const unsigned* __restrict__ max_key, double quality,
-                                                   int w, int cell, int gw, const int* __restrict__ cell_start,
-                                                   int* __restrict__ cell_fill,
+                                                   const unsigned* __restrict__ prune_key, int w, int cell, int gw,
+                                                   const int* __restrict__ cell_start, int* __restrict__ cell_fill,
                                                    unsigned long long* __restrict__ cell_cand,
                                                    uint8_t* __restrict__ state)
 {
     const float thr = threshold_of(max_key, quality);
+    const unsigned pk = *prune_key;
     for (int b = blockIdx.x; b < src.nblk; b += gridDim.x) {
         const int cnt = src.blk_count[b];
         for (int i = threadIdx.x; i < cnt; i += 256) {
             const unsigned long long key = src.keys[(size_t)b * src.region + i];
-            if (!(key_to_float((unsigned)(key >> 32)) > thr)) continue;
+            if ((unsigned)(key >> 32) < pk || !(key_to_float((unsigned)(key >> 32)) > thr)) continue;
             const unsigned idx = (unsigned)key;
             const int y = (int)(idx >> 16), x = (int)(idx & 0xffffu);
             const int c = (y / cell) * gw + (x / cell);
@@ -583,15 +638,23 @@ __global__ __launch_bounds__(256) void k_suppress(const unsigned long long* __re
 // zero every counter a detection uses, in one launch (each hipMemsetAsync is a ~5 us kernel of its own)
 __global__ void k_detect_reset(int* __restrict__ cell_count, int* __restrict__ cell_fill, int ncell,
                                int* __restrict__ undecided, int* __restrict__ acc_count,
-                               int* __restrict__ cand_count, unsigned* __restrict__ max_key)
+                               int* __restrict__ cand_count, unsigned* __restrict__ max_key,
+                               unsigned* __restrict__ key_hist, unsigned* __restrict__ prune_key, int full)
 {
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = i0; i <= ncell; i += gridDim.x * blockDim.x) {
         cell_count[i] = 0;
         if (i < ncell) cell_fill[i] = 0;
     }
+    if (full)
+        for (int i = i0; i < KEY_BINS; i += gridDim.x * blockDim.x) key_hist[i] = 0;
     if (i0 < 8) undecided[i0] = 0;
-    if (i0 == 0) { *acc_count = 0; *cand_count = 0; *max_key = 0; }
+    if (i0 == 0) {
+        *acc_count = 0;
+        *cand_count = 0;
+        *prune_key = 0;
+        if (full) *max_key = 0;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_gather_accepted(const unsigned long long* __restrict__ cell_cand,
@@ -696,10 +759,15 @@ static CandSrc src_of(const DetectScratch& D)
 }
 
 // First launch of every detection: zero the counters (ncell = 0 when minDistance < 1).
-void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell)
+// full = also the response maximum and the key histogram (i.e. everything a NEW detection needs); !full = only
+// what a re-run of the min-distance stage on the same candidates needs.
+void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, bool full)
 {
-    hipLaunchKernelGGL(k_detect_reset, dim3((ncell + 256) / 256 < 512 ? (ncell + 256) / 256 : 512), dim3(256), 0, s,
-                       D.cell_count, D.cell_fill, ncell, D.undecided, D.acc_count, D.cand_count, D.max_key);
+    int blocks = (ncell + 256) / 256;
+    if (full && blocks < KEY_BINS / 256) blocks = KEY_BINS / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(k_detect_reset, dim3(blocks), dim3(256), 0, s, D.cell_count, D.cell_fill, ncell, D.undecided,
+                       D.acc_count, D.cand_count, D.max_key, D.key_hist, D.prune_key, full ? 1 : 0);
 }
 
 // Candidate collection (K6+K7) into regions of D.acc_sorted (stream order, no host sync).
@@ -761,16 +829,22 @@ static void gather_launch(hipStream_t s, DetectScratch& D, int ncell)
                        D.acc_count);
 }
 
-void launch_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double min_distance, double quality)
+void launch_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double min_distance, double quality,
+                         int prune_want)
 {
     const int cell = (int)lrint(min_distance);
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     const int ncell = gw * gh;
-    hipLaunchKernelGGL(k_cell_count, dim3(1024), dim3(256), 0, s, src_of(D), D.max_key, quality, w, cell, gw, D.cell_count);
+    if (prune_want > 0) {
+        hipLaunchKernelGGL(k_key_hist, dim3(1024), dim3(256), 0, s, src_of(D), D.max_key, quality, D.key_hist);
+        hipLaunchKernelGGL(k_key_select, dim3(1), dim3(1024), 0, s, D.key_hist, (unsigned)prune_want, D.prune_key);
+    }
+    hipLaunchKernelGGL(k_cell_count, dim3(1024), dim3(256), 0, s, src_of(D), D.max_key, quality, D.prune_key, w, cell, gw,
+                       D.cell_count);
     hipLaunchKernelGGL(k_scan, dim3((ncell + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(1024), 0, s, D.cell_count,
                        D.cell_start, ncell);
-    hipLaunchKernelGGL(k_cell_fill, dim3(1024), dim3(256), 0, s, src_of(D), D.max_key, quality, w, cell, gw, D.cell_start,
-                       D.cell_fill, D.cell_cand, D.state);
+    hipLaunchKernelGGL(k_cell_fill, dim3(1024), dim3(256), 0, s, src_of(D), D.max_key, quality, D.prune_key, w, cell, gw,
+                       D.cell_start, D.cell_fill, D.cell_cand, D.state);
     suppress_launches(s, D, w, h, min_distance);
     gather_launch(s, D, ncell);
 }

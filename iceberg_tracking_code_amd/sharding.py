@@ -1,0 +1,56 @@
+"""Segment sharding across the GPUs of one node (one process per GPU) and the final gather.
+
+The independent unit of the reference loop is a SEGMENT: `track_len + 1` consecutive frames starting at a
+detection frame (`counter % track_len == 0`, s1_lucaskanade_tracking.py:362; tracks are reset there, s1:440).
+Frame pairs inside a segment are sequentially dependent (p1 of pair i is p0 of pair i+1), segments are not, so a
+rank takes a contiguous block of segments and needs one extra frame at the end of its block.  There is no
+collective on the data path; the only exchange is the gather of the per-segment track counts at the end
+(`torch.distributed` all_gather: RCCL over xGMI with backend "nccl", gloo in the CPU tests).
+"""
+import numpy as np
+
+
+def segment_count(n_frames, track_len):
+    """Completed segments in a sequence of n_frames (the loop saves a segment at every detection frame > 0)."""
+    if n_frames < track_len + 1:
+        return 0
+    return (n_frames - 1) // track_len
+
+
+def segment_block(n_segments, rank, world):
+    """[first, last) segment indices of `rank`: contiguous blocks, sizes differing by at most one."""
+    base, extra = divmod(n_segments, world)
+    first = rank * base + min(rank, extra)
+    return first, first + base + (1 if rank < extra else 0)
+
+
+def frame_block(n_frames, track_len, rank, world):
+    """[first, last) FRAME indices rank needs: its segments plus the closing frame of its last segment."""
+    s0, s1 = segment_block(segment_count(n_frames, track_len), rank, world)
+    if s1 <= s0:
+        return 0, 0
+    return s0 * track_len, s1 * track_len + 1
+
+
+def gather_counts(local_counts, dist=None, device=None):
+    """All ranks' per-segment track counts, concatenated in rank order (int64 numpy array).
+
+    `dist` is torch.distributed (initialised) or None for a single process.  Blocks are padded to the largest
+    block so that one all_gather suffices; messages are a few hundred bytes, i.e. latency bound on any fabric.
+    """
+    local = np.asarray(local_counts, np.int64).ravel()
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local.copy()
+    import torch
+    world = dist.get_world_size()
+    n = torch.tensor([local.size], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    pad = max(max(sizes), 1)
+    mine = torch.zeros(pad, dtype=torch.int64, device=device)
+    if local.size:
+        mine[:local.size] = torch.from_numpy(local).to(mine.device)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return np.concatenate([p[:k].cpu().numpy() for p, k in zip(parts, sizes)]) if sum(sizes) else np.zeros(0, np.int64)

@@ -213,8 +213,8 @@ class SegmentTracker:
         if detect:
             # the detector needs this frame only: start it first, on its own stream, so that it runs beside
             # the tracker launch below (the reference does them back to back, s1:323-326 then s1:437)
-            self.ctx.seg_detect_begin(slot, self.fp["qualityLevel"], self.fp["minDistance"], self.use_mask,
-                                      self.fp.get("blockSize", 3))
+            self.ctx.seg_detect_begin(slot, self.fp["maxCorners"], self.fp["qualityLevel"], self.fp["minDistance"],
+                                      self.use_mask, self.fp.get("blockSize", 3))
         if self.active:
             self.ctx.seg_track(prev, slot, self.lk["winSize"], self.lk["maxLevel"], self.lk["criteria"],
                                self.lk.get("minEigThreshold", 1e-4), self.fb_threshold, wait=False)

@@ -126,8 +126,8 @@ int icelk_seg_detect(icelk_t* h, int slot, int use_mask, int max_corners, double
 /* The same detection split in two, for pipelined loops: _begin enqueues the detector on the handle's
  * detection stream (it needs the frame only, so it overlaps a tracker launch issued after it) and returns
  * at once; _finish waits for it and starts the new segment. */
-int icelk_seg_detect_begin(icelk_t* h, int slot, int use_mask, double quality_level, double min_distance,
-                           int block_size);
+int icelk_seg_detect_begin(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level,
+                           double min_distance, int block_size);
 int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n);
 int icelk_seg_track(icelk_t* h, int slot_prev, int slot_next, int win_w, int win_h, int max_level,
                     int crit_type, int max_count, double epsilon, double min_eig_threshold,

@@ -282,3 +282,24 @@ def test_segment_tracker_equals_reference_loop(orc, synth, track_len):
         assert np.array_equal(gt.view(np.uint32), rt.view(np.uint32))
         assert np.array_equal(gq.view(np.uint32), rq.view(np.uint32))
         assert len(gt) > 100
+
+
+@pytest.mark.parametrize("maxc", [50, 400, 3000])
+def test_topk_pruning_is_invisible(ctx, orc, synth, maxc, monkeypatch):
+    """maxCorners-driven candidate pruning (and its unpruned fallback) must not change the corner list."""
+    img = synth.frame(900, 700, 3, 4, 11)
+    ctx.upload_gray(0, img)
+    ref = orc.good_features(img, maxc, 0.007, 10, None, 10)
+    pruned = ctx.good_features(0, maxc, 0.007, 10, False, 10)
+    monkeypatch.setenv("ICELK_NO_PRUNE", "1")
+    plain = ctx.good_features(0, maxc, 0.007, 10, False, 10)
+    monkeypatch.delenv("ICELK_NO_PRUNE")
+    assert np.array_equal(pruned, ref) and np.array_equal(plain, ref)
+    # a mask that leaves fewer corners than 8*maxCorners candidates can supply forces the fallback path
+    mask = np.zeros_like(img)
+    mask[100:220, 100:260] = 255
+    ctx.set_mask(mask)
+    got = ctx.good_features(0, maxc, 0.007, 10, True, 10)
+    exp = orc.good_features(img, maxc, 0.007, 10, mask, 10)
+    assert np.array_equal(got, exp)
+    ctx.set_mask(None)
