@@ -110,7 +110,7 @@ struct DetectScratch {
     void* sort_tmp;
     size_t sort_tmp_bytes;
     int* blk_count;        // candidates per producer workgroup (region layout, see k_corners.hip)
-    unsigned* key_hist;    // 65536 bins over the top 16 bits of the response key (top-K pruning)
+    unsigned* key_hist;    // histogram of the response keys (top-K pruning); 65536 entries allocated
     unsigned* prune_key;   // 1: candidates with a smaller response key are ignored (0 = none)
     int src_nblk, src_region;   // geometry of the candidate regions of the detection in flight
 };

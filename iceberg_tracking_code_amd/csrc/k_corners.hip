@@ -444,19 +444,30 @@ __global__ __launch_bounds__(256) void k_cell_count(CandSrc src, const unsigned*
 // Whether a candidate is accepted depends only on STRONGER candidates, so the accepted candidates among the K
 // strongest are exactly the greedy-accepted ones among them; if they number >= maxCorners, the weaker
 // candidates can never appear in the output and need not be binned, relaxed or sorted.  K is found from a
-// 65536-bin histogram of the response key (its top 16 bits); the host checks "accepted >= maxCorners" at its
+// 16384-bin histogram of the response key (its top 14 bits); the host checks "accepted >= maxCorners" at its
 // one synchronisation point and reruns unpruned otherwise.
-constexpr int KEY_BINS = 1 << 16;
+constexpr int KEY_SHIFT = 18;                 // bin = key >> 18: sign, exponent and 5 mantissa bits
+constexpr int KEY_BINS = 1 << (32 - KEY_SHIFT);
+// Responses cluster in a few hundred bins, so a global-memory histogram would serialise on a handful of L2
+// atomic addresses: every workgroup histograms into LDS and flushes its non-empty bins.
 __global__ __launch_bounds__(256) void k_key_hist(CandSrc src, const unsigned* __restrict__ max_key, double quality,
                                                   unsigned* __restrict__ hist)
 {
+    __shared__ unsigned lh[KEY_BINS];
+    for (int i = threadIdx.x; i < KEY_BINS; i += 256) lh[i] = 0;
+    __syncthreads();
     const float thr = threshold_of(max_key, quality);
     for (int b = blockIdx.x; b < src.nblk; b += gridDim.x) {
         const int cnt = src.blk_count[b];
         for (int i = threadIdx.x; i < cnt; i += 256) {
             const unsigned k = (unsigned)(src.keys[(size_t)b * src.region + i] >> 32);
-            if (key_to_float(k) > thr) atomicAdd(&hist[k >> 16], 1u);
+            if (key_to_float(k) > thr) atomicAdd(&lh[k >> KEY_SHIFT], 1u);
         }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < KEY_BINS; i += 256) {
+        const unsigned v = lh[i];
+        if (v) atomicAdd(&hist[i], v);
     }
 }
 
@@ -485,7 +496,7 @@ __global__ __launch_bounds__(1024) void k_key_select(const unsigned* __restrict_
         for (int i = PER - 1; i >= 0; i--) {
             run += hist[tid * PER + i];
             if (run >= want) {
-                *prune_key = (unsigned)(tid * PER + i) << 16;
+                *prune_key = (unsigned)(tid * PER + i) << KEY_SHIFT;
                 break;
             }
         }
@@ -836,7 +847,7 @@ void launch_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double m
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     const int ncell = gw * gh;
     if (prune_want > 0) {
-        hipLaunchKernelGGL(k_key_hist, dim3(1024), dim3(256), 0, s, src_of(D), D.max_key, quality, D.key_hist);
+        hipLaunchKernelGGL(k_key_hist, dim3(128), dim3(256), 0, s, src_of(D), D.max_key, quality, D.key_hist);
         hipLaunchKernelGGL(k_key_select, dim3(1), dim3(1024), 0, s, D.key_hist, (unsigned)prune_want, D.prune_key);
     }
     hipLaunchKernelGGL(k_cell_count, dim3(1024), dim3(256), 0, s, src_of(D), D.max_key, quality, D.prune_key, w, cell, gw,
