@@ -188,16 +188,15 @@ def main():
     elapsed = t1 - t0
     tracked = tracked1 - tracked0
 
-    # max over ranks of the elapsed time; RCCL all-gather of the per-rank feature counts
+    # max over ranks of the elapsed time; the one collective of the path: RCCL all-gather of the per-rank
+    # feature counts (sharding.gather_counts, also exercised under gloo in tests/test_host_logic.py)
     tracked_all = [tracked]
     if dist is not None:
+        from iceberg_tracking_code_amd import sharding
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor([tracked], dtype=torch.int64, device="cuda")
-        gathered = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        tracked_all = [int(g.item()) for g in gathered]
+        tracked_all = [int(v) for v in sharding.gather_counts([tracked], dist, device="cuda")]
 
     if rank == 0:
         top = top_level_of(w, h, cfg["win"], cfg["max_level"])
