@@ -57,12 +57,12 @@ struct Ctx {
     size_t ncell_cap = 0;
 
     // segment state
-    float* d_live[2] = {nullptr, nullptr};
-    int* d_origin[2] = {nullptr, nullptr};
-    int* d_nlive = nullptr;   // [2]
-    unsigned long long* d_tracked = nullptr;
+    float* d_live = nullptr;               // (max_pts,2) current position of every track of the segment
+    uint8_t* d_alive = nullptr;            // 1 while the track survives
+    unsigned long long* d_tracked = nullptr;   // 64 sharded counters
+    unsigned long long* h_seg = nullptr;   // pinned: {alive tracks, features tracked}
     float *d_tracks = nullptr, *d_quality = nullptr, *d_out_tracks = nullptr, *d_out_quality = nullptr;
-    int seg_cur = 0, seg_vert = 0, seg_upper = 0;
+    int seg_vert = 0, seg_upper = 0;   // vertices so far, tracks of the segment (= corners detected)
     bool seg_active = false;
 
     int last_candidates = 0, last_accepted = 0;   // of the latest detection
@@ -305,11 +305,12 @@ static void destroy_ctx(Ctx* c)
     if (c->corners_free) hipEventDestroy(c->corners_free);
     if (c->det_stream) hipStreamDestroy(c->det_stream);
     if (c->h_counts) hipHostFree(c->h_counts);
+    if (c->h_seg) hipHostFree(c->h_seg);
     void* ptrs[] = {c->d_bgr, c->d_mask, c->d_p0, c->d_p1, c->d_p0r, c->d_err_f, c->d_err_b, c->d_dist, c->d_corners,
                     c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.max_key, c->D.cand, c->D.cand_count,
                     c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.cell_cand, c->D.state, c->D.undecided,
-                    c->D.acc, c->D.acc_sorted, c->D.acc_count, c->D.blk_count, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->d_live[0], c->d_live[1],
-                    c->d_origin[0], c->d_origin[1], c->d_nlive, c->d_tracked, c->d_tracks, c->d_quality,
+                    c->D.acc, c->D.acc_sorted, c->D.acc_count, c->D.blk_count, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->d_live, c->d_alive,
+                    c->d_tracked, c->d_tracks, c->d_quality,
                     c->d_out_tracks, c->d_out_quality};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -499,10 +500,9 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
     rc = ensure_pyramid(c, slot_prev, P.top_level);
     if (!rc) rc = ensure_pyramid(c, slot_next, P.top_level);
     if (rc) return rc;
-    const int cur = c->seg_cur, nxt = cur ^ 1;
     if (c->seg_upper > 0) {
         LKBuffers B{};
-        B.p_in = c->d_live[cur];
+        B.p_in = c->d_live;
         B.p_fwd = c->d_p1;
         B.st_fwd = c->d_st_f;
         B.err_fwd = c->d_err_f;
@@ -511,7 +511,13 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
         B.err_bwd = c->d_err_b;
         B.dist = c->d_dist;
         B.valid = c->d_valid;
-        B.n_dev = c->d_nlive + cur;
+        B.seg_alive = c->d_alive;
+        B.seg_xy = c->d_live;
+        B.seg_tracks = c->d_tracks;
+        B.seg_quality = c->d_quality;
+        B.seg_vert = c->seg_vert;
+        B.seg_max_vert = kMaxVert;
+        B.seg_tracked = c->d_tracked;
         {
             ProfScope p(c, K_LK_FB);
             rc = launch_lk(c->stream, pyramid_of(s0), pyramid_of(s1), B, c->seg_upper, P, true);
@@ -520,15 +526,6 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
         rc = check_launch(c, "lk_fb");
         if (rc) return rc;
     }
-    {
-        ProfScope p(c, K_COMPACT);
-        launch_compact(c->stream, c->d_p1, c->d_dist, c->d_valid, c->d_origin[cur], c->d_nlive + cur, c->d_live[nxt],
-                       c->d_origin[nxt], c->d_nlive + nxt, c->d_tracks, c->d_quality, c->seg_vert, kMaxVert,
-                       c->d_tracked);
-    }
-    rc = check_launch(c, "compact");
-    if (rc) return rc;
-    c->seg_cur = nxt;
     c->seg_vert += 1;
     return ICELK_OK;
 }
@@ -586,6 +583,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         create_priority_stream(&c->det_stream) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&c->h_seg), 64, hipHostMallocMapped) != hipSuccess ||
         hipEventCreateWithFlags(&c->det_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->corners_free, hipEventDisableTiming) != hipSuccess) {
         c->err = "hipStreamCreate failed";
@@ -623,13 +621,12 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &D.acc, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.acc_sorted, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, &D.blk_count, candidate_blocks(max_w, max_h) * 4)) ||
         (rc = dmalloc(c, &D.key_hist, 1 << 16)) || (rc = dmalloc(c, &D.prune_key, 1)) || (rc = dmalloc(c, (uint8_t**)&D.sort_tmp, D.sort_tmp_bytes)) ||
-        (rc = dmalloc(c, &c->d_live[0], 2 * np)) || (rc = dmalloc(c, &c->d_live[1], 2 * np)) ||
-        (rc = dmalloc(c, &c->d_origin[0], np)) || (rc = dmalloc(c, &c->d_origin[1], np)) || (rc = dmalloc(c, &c->d_nlive, 2)) ||
-        (rc = dmalloc(c, &c->d_tracked, 1)) || (rc = dmalloc(c, &c->d_tracks, np * kMaxVert * 2)) ||
+        (rc = dmalloc(c, &c->d_live, 2 * np)) || (rc = dmalloc(c, &c->d_alive, np)) ||
+        (rc = dmalloc(c, &c->d_tracked, 64)) || (rc = dmalloc(c, &c->d_tracks, np * kMaxVert * 2)) ||
         (rc = dmalloc(c, &c->d_quality, np * (kMaxVert - 1))) || (rc = dmalloc(c, &c->d_out_tracks, np * kMaxVert * 2)) ||
         (rc = dmalloc(c, &c->d_out_quality, np * (kMaxVert - 1))))
         return fail(rc);
-    if (hipMemset(c->d_nlive, 0, 2 * sizeof(int)) != hipSuccess || hipMemset(c->d_tracked, 0, 8) != hipSuccess) {
+    if (hipMemset(c->d_tracked, 0, 64 * 8) != hipSuccess) {
         c->err = "hipMemset failed";
         return fail(ICELK_EHIP);
     }
@@ -1046,12 +1043,10 @@ int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n)
     int rc = detect_finish(c, max_corners, c->max_pts, &n);
     if (rc) return rc;
     if (n > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->det_done, 0));
-    launch_seg_init(c->stream, c->d_corners, n, c->d_live[0], c->d_origin[0], c->d_tracks, kMaxVert, c->d_nlive,
-                    c->d_tracked);
+    launch_seg_init(c->stream, c->d_corners, n, c->d_live, c->d_alive, c->d_tracks, kMaxVert);
     rc = check_launch(c, "seg_init");
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->corners_free, c->stream));
-    c->seg_cur = 0;
     c->seg_vert = 1;
     c->seg_upper = n;
     c->seg_active = true;
@@ -1083,12 +1078,12 @@ int icelk_seg_live(icelk_t* h, int* out_live, int64_t* out_tracked_total)
     Ctx* c = C(h);
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->seg_active) FAIL(c, ICELK_ESTATE, "icelk_seg_detect has not been called");
-    int n = 0;
-    unsigned long long t = 0;
-    HIPCHK(c, hipMemcpyAsync(&n, c->d_nlive + c->seg_cur, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&t, c->d_tracked, sizeof(t), hipMemcpyDeviceToHost, c->stream));
+    launch_seg_stats(c->stream, c->d_alive, c->seg_upper, c->d_tracked, c->h_seg);
+    int rc0 = check_launch(c, "seg_stats");
+    if (rc0) return rc0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->seg_upper = n;
+    const int n = (int)c->h_seg[0];
+    const unsigned long long t = c->h_seg[1];
     if (out_live) *out_live = n;
     if (out_tracked_total) *out_tracked_total = (int64_t)t;
     return ICELK_OK;
@@ -1118,8 +1113,8 @@ int icelk_seg_read(icelk_t* h, float* tracks, float* quality, int cap, int max_v
     if (!tracks && !quality) return ICELK_OK;
     if (n > cap || nv > max_vertices) FAIL(c, ICELK_ECAP, "host track buffers too small");
     if (n == 0) return ICELK_OK;
-    launch_seg_gather(c->stream, c->d_origin[c->seg_cur], c->d_nlive + c->seg_cur, n, c->d_tracks, c->d_quality, nv,
-                      kMaxVert, c->d_out_tracks, c->d_out_quality);
+    launch_seg_gather(c->stream, c->d_alive, c->seg_upper, c->d_tracks, c->d_quality, nv, kMaxVert, c->d_out_tracks,
+                      c->d_out_quality);
     rc = check_launch(c, "seg_gather");
     if (rc) return rc;
     // host layout: (n, max_vertices, 2) and (n, max_vertices-1) with the caller's vertex dimension

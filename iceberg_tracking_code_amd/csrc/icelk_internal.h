@@ -86,6 +86,16 @@ struct LKBuffers {
     float* dist;
     uint8_t* valid;
     const int* n_dev;    // optional device-side count (overrides n when non-null)
+    // Segment mode (icelk_seg_track): the launch itself keeps the track table.  Feature f is track f of the
+    // segment; dead tracks (seg_alive[f] == 0) exit at once, survivors of the forward-backward test get their
+    // new vertex and distance appended and their position updated in place -- the Python loop of
+    // s1_lucaskanade_tracking.py:335-359 without a separate compaction launch.
+    uint8_t* seg_alive;
+    float* seg_xy;               // (n,2) current position of every track; also the input points in this mode
+    float* seg_tracks;           // [track][max_vert][2]
+    float* seg_quality;          // [track][max_vert-1]
+    int seg_vert, seg_max_vert;  // vertex written by this launch
+    unsigned long long* seg_tracked;   // 64 sharded counters: features tracked (for throughput accounting)
 };
 size_t lk_lds_bytes(const LKParams& P);
 int launch_lk(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
@@ -138,14 +148,15 @@ void sort_keys_desc(hipStream_t s, DetectScratch& D, const unsigned long long* i
                     int n);
 void launch_emit_corners(hipStream_t s, const unsigned long long* keys, int n, int w, float* xy);
 
-// Segment bookkeeping (k_tracks.hip): stable compaction of survivors + track-table append.
-void launch_seg_init(hipStream_t s, const float* corners, int n, float* live_xy, int* origin, float* tracks,
-                     int max_vert, int* n_live, unsigned long long* tracked_total);
-void launch_compact(hipStream_t s, const float* p1, const float* dist, const uint8_t* valid, const int* origin_in,
-                    const int* n_in, float* live_out, int* origin_out, int* n_out, float* tracks, float* quality,
-                    int vert, int max_vert, unsigned long long* tracked_total);
-void launch_seg_gather(hipStream_t s, const int* origin, const int* n_live, int n_upper, const float* tracks,
-                       const float* quality, int nvert, int max_vert, float* out_tracks, float* out_quality);
+// Segment bookkeeping (k_tracks.hip).
+void launch_seg_init(hipStream_t s, const float* corners, int n, float* xy, uint8_t* alive, float* tracks,
+                     int max_vert);
+// {alive tracks, features tracked so far} -> host_out[0..1] (pinned, 64-bit each)
+void launch_seg_stats(hipStream_t s, const uint8_t* alive, int n, const unsigned long long* tracked_shards,
+                      unsigned long long* host_out);
+// rows of the alive tracks, in track order, packed into out_tracks (n_alive, nvert, 2) / out_quality
+void launch_seg_gather(hipStream_t s, const uint8_t* alive, int n, const float* tracks, const float* quality,
+                       int nvert, int max_vert, float* out_tracks, float* out_quality);
 size_t min_eig_lds_bytes(int block_size);
 
 }  // namespace icelk

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(64) void k_lk(Pyramid PI, Pyramid PJ, LKBuffers B, 
     const int f = blockIdx.x;
     const int count = B.n_dev ? *B.n_dev : n;
     if (f >= count) return;
+    if (B.seg_alive && !B.seg_alive[f]) return;
     const int lane = threadIdx.x;
     const float p0x = B.p_in[2 * f], p0y = B.p_in[2 * f + 1];
     const bool init = (P.flags & ICELK_FLAG_INITIAL_FLOW) != 0;
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(64) void k_lk(Pyramid PI, Pyramid PJ, LKBuffers B, 
             const float d = sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
             if (B.dist) B.dist[f] = d;
             if (B.valid) B.valid[f] = d < P.fb_thr ? 1 : 0;
+            if (B.seg_alive) seg_append(B, f, r1.x, r1.y, d, d < P.fb_thr);
         }
     }
 }

@@ -442,6 +442,7 @@ __global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : 2)) void k_lk_fast
     const int f = blockIdx.x;
     const int count = B.n_dev ? *B.n_dev : n;
     if (f >= count) return;
+    if (B.seg_alive && !B.seg_alive[f]) return;
     const int lane = threadIdx.x;
     uint32_t* ldsI = lds;
     uint32_t* ldsJ = lds + C::I_DW;
@@ -462,6 +463,7 @@ __global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : 2)) void k_lk_fast
             const float d = sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
             if (B.dist) B.dist[f] = d;
             if (B.valid) B.valid[f] = d < P.fb_thr ? 1 : 0;
+            if (B.seg_alive) seg_append(B, f, r1.x, r1.y, d, d < P.fb_thr);
         }
     }
 }

@@ -87,6 +87,21 @@ __device__ __forceinline__ long long wave_sum_exact(int v)
     return ((long long)hi << 16) + (long long)lo;
 }
 
+// segment-mode epilogue of a fused forward+backward launch (one lane per feature calls it)
+__device__ __forceinline__ void seg_append(const LKBuffers& B, int f, float x, float y, float d, bool valid)
+{
+    B.seg_alive[f] = valid ? 1 : 0;
+    if (valid) {
+        B.seg_xy[2 * f] = x;
+        B.seg_xy[2 * f + 1] = y;
+        float* t = B.seg_tracks + ((size_t)f * B.seg_max_vert + B.seg_vert) * 2;
+        t[0] = x;
+        t[1] = y;
+        B.seg_quality[(size_t)f * (B.seg_max_vert - 1) + (B.seg_vert - 1)] = d;
+    }
+    atomicAdd(&B.seg_tracked[f & 63], 1ull);
+}
+
 template <bool SMALL, int G>
 __device__ __forceinline__ long long sum_pick(int v)
 {
