@@ -145,7 +145,6 @@ __global__ __launch_bounds__(256) void k_eig_nms(const uint8_t* __restrict__ img
     const int x0 = blockIdx.x * C::TW, y0 = blockIdx.y * C::TH;
     const int ux0 = x0 - 2 - C::AN, uy0 = y0 - 2 - C::AN;   // image coordinate of U(0,0)
     const bool interior = ux0 >= 0 && uy0 >= 0 && ux0 + C::UW <= w && uy0 + C::UH <= h;
-    constexpr int NQ = C::CWP / 4;
     constexpr int COVP = C::CH * C::CWP;   // plane stride
 
     if (interior) {
@@ -156,10 +155,12 @@ __global__ __launch_bounds__(256) void k_eig_nms(const uint8_t* __restrict__ img
             U[i] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * c);
         }
         __syncthreads();
-        // 1b. covariance products, 4 positions per task
+        // 1b. covariance products, 4 positions per task over the full quads of a row (18 x 27 tasks = two
+        //     rounds of 256 threads for blockSize 10); the 0..3 leftover columns are done one position per lane
         const int cs = ux0 & 3;
-        for (int t = tid; t < C::CH * NQ; t += 256) {
-            const int cy = t / NQ, q = t - cy * NQ;
+        constexpr int NQF = C::CW / 4, REM = C::CW - 4 * NQF;
+        for (int t = tid; t < C::CH * NQF; t += 256) {
+            const int cy = t / NQF, q = t - cy * NQF;
             int B[3][6];
 #pragma unroll
             for (int r = 0; r < 3; r++) {
@@ -179,6 +180,20 @@ __global__ __launch_bounds__(256) void k_eig_nms(const uint8_t* __restrict__ img
             *reinterpret_cast<float4*>(c) = make_float4(xx[0], xx[1], xx[2], xx[3]);
             *reinterpret_cast<float4*>(c + COVP) = make_float4(xy[0], xy[1], xy[2], xy[3]);
             *reinterpret_cast<float4*>(c + 2 * COVP) = make_float4(yy[0], yy[1], yy[2], yy[3]);
+        }
+        if (REM > 0) {
+            const uint8_t* Ub = reinterpret_cast<const uint8_t*>(U);
+            for (int i = tid; i < C::CH * REM; i += 256) {
+                const int cy = i / REM, cx = 4 * NQF + (i - cy * REM);
+                const uint8_t* r0 = Ub + cy * C::UPD * 4 + cs + cx;
+                const uint8_t* r1 = r0 + C::UPD * 4;
+                const uint8_t* r2 = r1 + C::UPD * 4;
+                float xx, xy, yy;
+                sobel_cov((float)r0[0], (float)r0[1], (float)r0[2], (float)r1[0], (float)r1[2], (float)r2[0], (float)r2[1],
+                          (float)r2[2], k0, k1, xx, xy, yy);
+                float* c = cov + cy * C::CWP + cx;
+                c[0] = xx; c[COVP] = xy; c[2 * COVP] = yy;
+            }
         }
     } else {
         // border tiles: covariance at the reflected position (boxFilter reflects the covariance image, Sobel
@@ -201,11 +216,12 @@ __global__ __launch_bounds__(256) void k_eig_nms(const uint8_t* __restrict__ img
     __syncthreads();
 
     // 2. row sums: hs[p][cy][ex] = sum_{k<BS} cov[p][cy][ex+k], left to right, in double
+    //    one (plane, row, 6-output group) per task: 3 x 27 x 11 = 891 tasks fill the 256 threads in 4 rounds
     constexpr int HSP = C::CH * C::EW;
-    for (int t = tid; t < C::CH * C::NGX; t += 256) {
-        const int cy = t / C::NGX, g = t - cy * C::NGX;
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
+    for (int t = tid; t < 3 * C::CH * C::NGX; t += 256) {
+        const int p = t / (C::CH * C::NGX), t2 = t - p * (C::CH * C::NGX);
+        const int cy = t2 / C::NGX, g = t2 - cy * C::NGX;
+        {
             const float* c = cov + p * COVP + cy * C::CWP + g * C::RX;
             double v[C::RX + BS - 1];
 #pragma unroll
