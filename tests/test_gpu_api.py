@@ -1,0 +1,106 @@
+"""GPU: the cv2-shaped module surface (api.py), the reference-shaped loops driven through it, and the pinned
+double-buffered streaming ingest (BASELINE.json configs[0] and configs[2])."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class OracleCv:
+    def __init__(self, orc):
+        self.o = orc
+
+    def calcOpticalFlowPyrLK(self, a, b, p0, p1, **kw):
+        return self.o.pyrlk(a, b, p0, p1, **kw)
+
+    def goodFeaturesToTrack(self, img, mask=None, **kw):
+        return self.o.good_features(img, kw["maxCorners"], kw["qualityLevel"], kw["minDistance"], mask,
+                                    kw.get("blockSize", 3))
+
+
+def test_cv2_shaped_functions(orc, synth):
+    import iceberg_tracking_code_amd as cv2
+    rgb = synth.rgb_from_gray_seeded(321, 200, 10, -20, 8)
+    gray = cv2.cvtColor(rgb, cv2.COLOR_BGR2GRAY)
+    assert gray.dtype == np.uint8 and gray.shape == (200, 321)
+    assert np.array_equal(gray, orc.bgr2gray(rgb, 3))
+    # the reference hands PIL's RGB arrays to COLOR_BGR2GRAY (s1:310-311): channel 0 gets the 0.114 weight
+    assert np.array_equal(cv2.cvtColor(rgb, cv2.COLOR_RGB2GRAY), orc.bgr2gray(rgb[:, :, ::-1].copy(), 3))
+    cv2.set_gray_variant(4)
+    assert np.array_equal(cv2.cvtColor(rgb, cv2.COLOR_BGR2GRAY), orc.bgr2gray(rgb, 4))
+    cv2.set_gray_variant(3)
+    a, b = synth.frame(400, 300, 0, 0, 5), synth.frame(400, 300, 200, 300, 5)
+    mask = np.zeros_like(a)
+    mask[:, 100:] = 255
+    p = cv2.goodFeaturesToTrack(a, mask=mask, **cv2.REF_FEATURE_PARAMS)
+    assert np.array_equal(p, orc.good_features(a, 50000000, 0.007, 10, mask, 10)) and p.shape[1:] == (1, 2)
+    p1, st, err = cv2.calcOpticalFlowPyrLK(a, b, p, None, **cv2.REF_LK_PARAMS)
+    q1, qs, qe = orc.pyrlk(a, b, p, None, **cv2.REF_LK_PARAMS)
+    assert p1.shape == (len(p), 1, 2) and st.shape == (len(p), 1) and err.shape == (len(p), 1)
+    assert np.array_equal(p1.view(np.uint32), q1.view(np.uint32)) and np.array_equal(st, qs)
+    assert np.array_equal(err.view(np.uint32), qe.view(np.uint32))
+    assert cv2.goodFeaturesToTrack(np.full((60, 80), 3, np.uint8), 10, 0.01, 5) is None
+    cv2.release()
+
+
+def test_reference_loops_through_the_gpu_module(orc, synth):
+    """The s1-shaped loop and the s0_1-shaped class give the same lists on the GPU module and on the oracle."""
+    import iceberg_tracking_code_amd as cv2
+    frames, _ = synth.sequence(320, 240, 5, seed=3, max_step_px=2.0)
+    fp = dict(maxCorners=150, qualityLevel=0.007, minDistance=10, blockSize=10)
+    lk = dict(winSize=(35, 35), maxLevel=4, criteria=(3, 25, 0.03))
+    got = cv2.run_reference_loop(frames, 2, fp, lk, cv=cv2.api)
+    ref = cv2.run_reference_loop(frames, 2, fp, lk, cv=OracleCv(orc))
+    assert len(got) == len(ref) == 2
+    for (gf, gt, gq), (rf, rt, rq) in zip(got, ref):
+        assert gf == rf and np.array_equal(np.float32(gt), np.float32(rt)) and np.array_equal(np.float32(gq), np.float32(rq))
+    # BASELINE.json configs[0]: two 640x480 frames, 200 corners, through the s0_1-shaped class
+    f2, _ = synth.sequence(640, 480, 2, seed=1234)
+    fp200 = dict(maxCorners=200, qualityLevel=0.007, minDistance=10, blockSize=10)
+    a = cv2.LucasKanade(f2, 3, 120, cv=cv2.api, feature_params=fp200)
+    b = cv2.LucasKanade(f2, 3, 120, cv=OracleCv(orc), feature_params=fp200)
+    ta, tb = a.run(), b.run()
+    assert a.track_counts == b.track_counts == [0] and len(ta) == len(tb) > 150
+    assert np.array_equal(np.float32(ta), np.float32(tb))
+    cv2.release()
+
+
+def test_pinned_streaming_equals_blocking_upload(synth):
+    """icelk_upload_gray_async from pinned memory (copy stream + events) must give the segments of the blocking path."""
+    from iceberg_tracking_code_amd import SegmentTracker, _lib
+    w, h, n = 512, 384, 7
+    frames, _ = synth.sequence(w, h, n, seed=9, max_step_px=2.0)
+    fp = dict(maxCorners=500, qualityLevel=0.007, minDistance=10, blockSize=10)
+    lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
+
+    def run(pinned):
+        trk = SegmentTracker(w, h, 2, fp, lk, max_pts=4096)
+        segs, bufs = [], []
+        lib = _lib.load()
+        for i, f in enumerate(frames):
+            if pinned:
+                # two pinned buffers, refilled alternately: the copy of frame i+1 may overlap the kernels of frame i
+                if len(bufs) < 2:
+                    ptr = C.c_void_p()
+                    assert lib.icelk_host_alloc(C.byref(ptr), w * h) == 0
+                    bufs.append(ptr)
+                ptr = bufs[i % 2]
+                trk.ctx.sync()   # the buffer's previous copy has been consumed
+                C.memmove(ptr, f.ctypes.data, w * h)
+                s = trk.push_pinned(ptr.value, w)
+            else:
+                s = trk.push(f)
+            if s is not None:
+                segs.append(s)
+        trk.ctx.sync()
+        trk.close()
+        for ptr in bufs:
+            lib.icelk_host_free(ptr)
+        return segs
+
+    a, b = run(False), run(True)
+    assert len(a) == len(b) == 3
+    for (fa, ta, qa), (fb, tb, qb) in zip(a, b):
+        assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb) and len(ta) > 300
