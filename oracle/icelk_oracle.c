@@ -113,9 +113,17 @@ int orc_pyrdown(const uint8_t* src, int w, int h, int src_stride, uint8_t* dst, 
 {
     if (!src || !dst || w <= 0 || h <= 0) return ORC_EARG;
     int dw = (w + 1) / 2, dh = (h + 1) / 2;
+    int failed = 0;
+#pragma omp parallel
+    {
     int* rows = (int*)malloc(sizeof(int) * (size_t)dw * 5);
-    if (!rows) return ORC_ENOMEM;
+    if (!rows) {
+#pragma omp atomic write
+        failed = 1;
+    }
+#pragma omp for schedule(static)
     for (int dy = 0; dy < dh; dy++) {
+        if (!rows) continue;
         for (int k = 0; k < 5; k++) {
             int sy = reflect101(2 * dy - 2 + k, h);
             const uint8_t* s = src + (size_t)sy * src_stride;
@@ -133,7 +141,8 @@ int orc_pyrdown(const uint8_t* src, int w, int h, int src_stride, uint8_t* dst, 
         }
     }
     free(rows);
-    return ORC_OK;
+    }
+    return failed ? ORC_ENOMEM : ORC_OK;
 }
 
 /* A.2 number of pyramid levels actually built: stop when the NEXT level would not exceed winSize. */
@@ -154,10 +163,18 @@ int orc_pyramid_levels(int w, int h, int win_w, int win_h, int max_level)
 int orc_scharr(const uint8_t* src, int w, int h, int src_stride, int16_t* dst, int dst_stride_elems)
 {
     if (!src || !dst || w <= 0 || h <= 0) return ORC_EARG;
+    int failed = 0;
+#pragma omp parallel
+    {
     int* t0 = (int*)malloc(sizeof(int) * (size_t)(w + 2) * 2);
-    if (!t0) return ORC_ENOMEM;
-    int* t1 = t0 + (w + 2);
+    if (!t0) {
+#pragma omp atomic write
+        failed = 1;
+    }
+    int* t1 = t0 ? t0 + (w + 2) : NULL;
+#pragma omp for schedule(static)
     for (int y = 0; y < h; y++) {
+        if (!t0) continue;
         const uint8_t* r0 = src + (size_t)reflect101(y - 1, h) * src_stride;
         const uint8_t* r1 = src + (size_t)y * src_stride;
         const uint8_t* r2 = src + (size_t)reflect101(y + 1, h) * src_stride;
@@ -175,7 +192,8 @@ int orc_scharr(const uint8_t* src, int w, int h, int src_stride, int16_t* dst, i
         }
     }
     free(t0);
-    return ORC_OK;
+    }
+    return failed ? ORC_ENOMEM : ORC_OK;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -199,7 +217,17 @@ static int make_level(orc_level* L, int w, int h, int bw, int bh)
 
 static void pad_level(orc_level* L, int bw, int bh)
 {
+    /* rows inside the image first (left/right borders), then the rows above and below copy finished rows */
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < L->h; y++) {
+        uint8_t* d = L->img + (ptrdiff_t)y * L->pw;
+        for (int x = 1; x <= bw; x++) {
+            d[-x] = d[reflect101(-x, L->w)];
+            d[L->w - 1 + x] = d[reflect101(L->w - 1 + x, L->w)];
+        }
+    }
     for (int y = -bh; y < L->h + bh; y++) {
+        if (y >= 0 && y < L->h) continue;
         int sy = reflect101(y, L->h);
         uint8_t* d = L->img + (ptrdiff_t)y * L->pw;
         const uint8_t* s = L->img + (ptrdiff_t)sy * L->pw;
