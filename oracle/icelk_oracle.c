@@ -47,6 +47,7 @@
 #include <omp.h>
 #endif
 
+#define ORC_PAR_MIN_PIXELS 500000L
 #define ORC_OK 0
 #define ORC_EARG -1
 #define ORC_ENOMEM -2
@@ -114,7 +115,8 @@ int orc_pyrdown(const uint8_t* src, int w, int h, int src_stride, uint8_t* dst, 
     if (!src || !dst || w <= 0 || h <= 0) return ORC_EARG;
     int dw = (w + 1) / 2, dh = (h + 1) / 2;
     int failed = 0;
-#pragma omp parallel
+    /* small images: a parallel region costs more than the work (128 spinning threads on the GPU box) */
+#pragma omp parallel if ((long)w * h > ORC_PAR_MIN_PIXELS)
     {
     int* rows = (int*)malloc(sizeof(int) * (size_t)dw * 5);
     if (!rows) {
@@ -164,7 +166,7 @@ int orc_scharr(const uint8_t* src, int w, int h, int src_stride, int16_t* dst, i
 {
     if (!src || !dst || w <= 0 || h <= 0) return ORC_EARG;
     int failed = 0;
-#pragma omp parallel
+#pragma omp parallel if ((long)w * h > ORC_PAR_MIN_PIXELS)
     {
     int* t0 = (int*)malloc(sizeof(int) * (size_t)(w + 2) * 2);
     if (!t0) {
@@ -218,7 +220,7 @@ static int make_level(orc_level* L, int w, int h, int bw, int bh)
 static void pad_level(orc_level* L, int bw, int bh)
 {
     /* rows inside the image first (left/right borders), then the rows above and below copy finished rows */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((long)L->w * L->h > ORC_PAR_MIN_PIXELS)
     for (int y = 0; y < L->h; y++) {
         uint8_t* d = L->img + (ptrdiff_t)y * L->pw;
         for (int x = 1; x <= bw; x++) {
@@ -359,7 +361,7 @@ int orc_pyrlk(const uint8_t* prev, int prev_stride, const uint8_t* next, int nex
         orc_scharr(LI->img, cols, rows, LI->pw, deriv, 2 * dpw);
         const int dstep = 2 * dpw, stepI = LI->pw, stepJ = LJ->pw;
 
-#pragma omp parallel
+#pragma omp parallel if (n > 256)
         {
             int16_t* Iwin = (int16_t*)malloc(sizeof(int16_t) * 3 * (size_t)win_w * win_h);
             int16_t* dIwin = Iwin + (size_t)win_w * win_h;
@@ -542,7 +544,7 @@ int orc_min_eig_map(const uint8_t* img, int w, int h, int stride, int block_size
     float* rdy = rdx + npx;
 
     /* row pass: Dx uses [-1 0 1] (exact), Dy uses [k1 k0 k1] accumulated left to right */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((long)w * h > ORC_PAR_MIN_PIXELS)
     for (int y = 0; y < h; y++) {
         const uint8_t* s = img + (size_t)y * stride;
         for (int x = 0; x < w; x++) {
@@ -555,7 +557,7 @@ int orc_min_eig_map(const uint8_t* img, int w, int h, int stride, int block_size
         }
     }
     /* column pass + covariance products */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((long)w * h > ORC_PAR_MIN_PIXELS)
     for (int y = 0; y < h; y++) {
         int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
         for (int x = 0; x < w; x++) {
@@ -569,7 +571,7 @@ int orc_min_eig_map(const uint8_t* img, int w, int h, int stride, int block_size
     }
     /* unnormalised box filter, anchor = block_size/2, reflect-101, double sums */
     const int anchor = block_size / 2;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((long)w * h > ORC_PAR_MIN_PIXELS)
     for (int y = 0; y < h; y++) {
         for (int x = 0; x < w; x++) {
             double s0 = 0, s1 = 0, s2 = 0;
@@ -581,7 +583,7 @@ int orc_min_eig_map(const uint8_t* img, int w, int h, int stride, int block_size
             r[0] = s0; r[1] = s1; r[2] = s2;
         }
     }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((long)w * h > ORC_PAR_MIN_PIXELS)
     for (int y = 0; y < h; y++) {
         for (int x = 0; x < w; x++) {
             double s0 = 0, s1 = 0, s2 = 0;

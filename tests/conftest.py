@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the oracle's OpenMP regions are tiny in the tests; 100+ spinning threads (GPU box) only slow them down
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
