@@ -70,13 +70,16 @@ struct TileRegs {
 template <int PD, int TH>
 __device__ __forceinline__ void tile_issue(TileRegs<PD, TH>& t, const Level& L, int x0, int y0, int lane)
 {
+    // uniform 64-bit base + per-lane 32-bit offset (r * pitch + 4c < 2^24): one 24-bit mad per load, and no
+    // predication -- surplus lanes of the last round re-load the tile's last dword
     const uint8_t* base = L.ptr + (size_t)y0 * L.pitch + (x0 & ~3);
 #pragma unroll
     for (int m = 0; m < TileRegs<PD, TH>::N; m++) {
-        const int i = lane + 64 * m;
+        int i = lane + 64 * m;
+        i = i < PD * TH ? i : PD * TH - 1;
         const int r = i / PD, c = i - r * PD;
-        t.v[m] = 0;
-        if (i < PD * TH) t.v[m] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * L.pitch + 4 * c);
+        const unsigned off = (unsigned)__mul24(r, L.pitch) + 4u * (unsigned)c;
+        t.v[m] = *reinterpret_cast<const uint32_t*>(base + off);
     }
 }
 
@@ -85,8 +88,9 @@ __device__ __forceinline__ void tile_commit(const TileRegs<PD, TH>& t, uint32_t*
 {
 #pragma unroll
     for (int m = 0; m < TileRegs<PD, TH>::N; m++) {
-        const int i = lane + 64 * m;
-        if (i < PD * TH) lds[i] = t.v[m];
+        int i = lane + 64 * m;
+        i = i < PD * TH ? i : PD * TH - 1;   // same value written twice: harmless
+        lds[i] = t.v[m];
     }
 }
 
@@ -104,7 +108,21 @@ __device__ __forceinline__ void tile_border(uint32_t* lds, const Level& L, int x
 
 __device__ __forceinline__ bool tile_inside(const Level& L, int x0, int y0, int tw, int th)
 {
-    return x0 >= 0 && y0 >= 0 && x0 + tw <= L.w && y0 + th <= L.h;
+    // 0 <= x0 <= w - tw and 0 <= y0 <= h - th, as two unsigned compares (a level smaller than the tile fails)
+    return L.w >= tw && L.h >= th && (unsigned)x0 <= (unsigned)(L.w - tw) && (unsigned)y0 <= (unsigned)(L.h - th);
+}
+
+// OpenCV's bounds test of a window origin: !(x < -W || x >= cols || y < -H || y >= rows)
+template <int WW, int WH>
+__device__ __forceinline__ bool origin_ok(const Level& L, int x, int y)
+{
+    return (unsigned)(x + WW) < (unsigned)(L.w + WW) && (unsigned)(y + WH) < (unsigned)(L.h + WH);
+}
+
+// the staged search tile (origin jx0, jy0, margin R on every side) still covers a window at (x, y)
+__device__ __forceinline__ bool tile_covers(int jx0, int jy0, int x, int y)
+{
+    return (unsigned)(x - jx0) <= 2u * kMargin && (unsigned)(y - jy0) <= 2u * kMargin;
 }
 
 typedef short v2s __attribute__((ext_vector_type(2)));
@@ -191,7 +209,7 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
         else { sx = sx * 2.f; sy = sy * 2.f; }
         px -= half_x; py -= half_y;
         const int ipx = uni((int)floorf(px)), ipy = uni((int)floorf(py));
-        if (ipx < -WW || ipx >= LI.w || ipy < -WH || ipy >= LI.h) {
+        if (!origin_ok<WW, WH>(LI, ipx, ipy)) {
             if (level == 0) { Rz.status = 0; Rz.err = 0.f; }
             continue;
         }
@@ -205,7 +223,7 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
         const bool i_inside = tile_inside(LI, ix0, iy0, C::ITW, C::ITH);
         {
             const int inx = uni((int)floorf(nx)), iny = uni((int)floorf(ny));
-            const bool j_ok = !(inx < -WW || inx >= LJ.w || iny < -WH || iny >= LJ.h);
+            const bool j_ok = origin_ok<WW, WH>(LJ, inx, iny);
             const int tjx = inx - R, tjy = iny - R;
             const bool j_inside = j_ok && tile_inside(LJ, tjx, tjy, C::JTW, C::JTH);
             __syncthreads();
@@ -335,11 +353,11 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < P.max_count; j++) {
             const int inx = uni((int)floorf(nx)), iny = uni((int)floorf(ny));
-            if (inx < -WW || inx >= LJ.w || iny < -WH || iny >= LJ.h) {
+            if (!origin_ok<WW, WH>(LJ, inx, iny)) {
                 if (level == 0) Rz.status = 0;
                 break;
             }
-            if (!staged || inx < jx0 || inx > jx0 + 2 * R || iny < jy0 || iny > jy0 + 2 * R) {
+            if (!staged || !tile_covers(jx0, jy0, inx, iny)) {
                 jx0 = inx - R; jy0 = iny - R;
                 __syncthreads();
                 if (tile_inside(LJ, jx0, jy0, C::JTW, C::JTH)) {
@@ -391,11 +409,11 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
         if (Rz.status && level == 0 && !(P.flags & ICELK_FLAG_MIN_EIGENVALS)) {
             const float qx = sx - half_x, qy = sy - half_y;
             const int iqx = uni((int)floorf(qx)), iqy = uni((int)floorf(qy));
-            if (iqx < -WW || iqx >= LJ.w || iqy < -WH || iqy >= LJ.h) {
+            if (!origin_ok<WW, WH>(LJ, iqx, iqy)) {
                 Rz.status = 0;
                 continue;
             }
-            if (!staged || iqx < jx0 || iqx > jx0 + 2 * R || iqy < jy0 || iqy > jy0 + 2 * R) {
+            if (!staged || !tile_covers(jx0, jy0, iqx, iqy)) {
                 jx0 = iqx - R; jy0 = iqy - R;
                 __syncthreads();
                 if (tile_inside(LJ, jx0, jy0, C::JTW, C::JTH)) {
