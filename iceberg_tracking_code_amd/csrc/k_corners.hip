@@ -77,6 +77,21 @@ __device__ __forceinline__ void sobel_cov(float a0, float b0, float c0, float a1
     yy = __fmul_rn(dy, dy);
 }
 
+// the same for two horizontally adjacent positions at once, on packed f32 math (v_pk_add/mul_f32: two lanes of
+// work per issue slot); every operation rounds exactly like its scalar counterpart
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sobel_cov2(f2 a0, f2 b0, f2 c0, f2 a1, f2 c1, f2 a2, f2 b2, f2 c2, float k0, float k1,
+                                           f2& xx, f2& xy, f2& yy)
+{
+    const f2 dx = ((c0 - a0) + (c2 - a2)) * k1 + (c1 - a1) * k0;
+    const f2 t0 = (a0 * k1 + b0 * k0) + c0 * k1;
+    const f2 t2 = (a2 * k1 + b2 * k0) + c2 * k1;
+    const f2 dy = t2 - t0;
+    xx = dx * dx;
+    xy = dx * dy;
+    yy = dy * dy;
+}
+
 __device__ __forceinline__ float min_eig_of(double s0, double s1, double s2)
 {
     const float a = __fmul_rn((float)s0, 0.5f), b = (float)s1, c = __fmul_rn((float)s2, 0.5f);
@@ -171,15 +186,24 @@ __global__ __launch_bounds__(256) void k_eig_nms(const uint8_t* __restrict__ img
                 B[r][0] = e0 & 255; B[r][1] = (e0 >> 8) & 255; B[r][2] = (e0 >> 16) & 255; B[r][3] = e0 >> 24;
                 B[r][4] = e1 & 255; B[r][5] = (e1 >> 8) & 255;
             }
-            float xx[4], xy[4], yy[4];
+            float F[3][6];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                sobel_cov((float)B[0][i], (float)B[0][i + 1], (float)B[0][i + 2], (float)B[1][i], (float)B[1][i + 2],
-                          (float)B[2][i], (float)B[2][i + 1], (float)B[2][i + 2], k0, k1, xx[i], xy[i], yy[i]);
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int i = 0; i < 6; i++) F[r][i] = (float)B[r][i];
+            f2 xx[2], xy[2], yy[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int j = 2 * i;
+                sobel_cov2(f2{F[0][j], F[0][j + 1]}, f2{F[0][j + 1], F[0][j + 2]}, f2{F[0][j + 2], F[0][j + 3]},
+                           f2{F[1][j], F[1][j + 1]}, f2{F[1][j + 2], F[1][j + 3]},
+                           f2{F[2][j], F[2][j + 1]}, f2{F[2][j + 1], F[2][j + 2]}, f2{F[2][j + 2], F[2][j + 3]},
+                           k0, k1, xx[i], xy[i], yy[i]);
+            }
             float* c = cov + cy * C::CWP + 4 * q;
-            *reinterpret_cast<float4*>(c) = make_float4(xx[0], xx[1], xx[2], xx[3]);
-            *reinterpret_cast<float4*>(c + COVP) = make_float4(xy[0], xy[1], xy[2], xy[3]);
-            *reinterpret_cast<float4*>(c + 2 * COVP) = make_float4(yy[0], yy[1], yy[2], yy[3]);
+            *reinterpret_cast<float4*>(c) = make_float4(xx[0].x, xx[0].y, xx[1].x, xx[1].y);
+            *reinterpret_cast<float4*>(c + COVP) = make_float4(xy[0].x, xy[0].y, xy[1].x, xy[1].y);
+            *reinterpret_cast<float4*>(c + 2 * COVP) = make_float4(yy[0].x, yy[0].y, yy[1].x, yy[1].y);
         }
         if (REM > 0) {
             const uint8_t* Ub = reinterpret_cast<const uint8_t*>(U);
@@ -839,7 +863,7 @@ void launch_flatten(hipStream_t s, DetectScratch& D, double quality)
 // D.acc (unsorted accepted keys), D.acc_count; the number of thresholded candidates ends in
 // D.cell_start[ncell].  D.undecided[kSuppressLaunches-1] != 0 afterwards means "not converged, call
 // continue_min_distance".
-constexpr int kSuppressLaunches = 4;
+constexpr int kSuppressLaunches = 2;
 static void suppress_launches(hipStream_t s, DetectScratch& D, int w, int h, double min_distance)
 {
     const int cell = (int)lrint(min_distance);
