@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- frame-pairs/s and tracked-features/s of the sparse LK tracking loop on MI355X.
 
-    python bench.py --gpus 1 --steps 40 --warmup 4
+    python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -123,11 +123,16 @@ def cpu_baseline(cfg, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--ring", type=int, default=24, help="distinct frames resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="start a detection only when its frame is pushed (A/B of the cross-step overlap)")
+    ap.add_argument("--source", default="hbm", choices=("hbm", "host"),
+                    help="hbm: frames resident in HBM (the headline number); host: every frame crosses PCIe from "
+                         "pinned host memory, uploads double-buffered against the tracker (BASELINE.json configs[2])")
     args = ap.parse_args()
 
     import torch
@@ -149,17 +154,28 @@ def main():
     w, h = cfg["w"], cfg["h"]
     K, W = args.steps, args.warmup
     ring = max(2, min(args.ring, K + W + 1))
+    host = args.source == "host"
+    if host:
+        ring = min(ring, 8)
     max_pts = max(cfg["max_corners"], 1 << 14) if cfg["max_corners"] > 0 else 1 << 18
-    ctx = Context(w, h, n_slots=ring, max_pts=max_pts, device=local_rank)
+    ctx = Context(w, h, n_slots=4 if host else ring, max_pts=max_pts, device=local_rank)
     from iceberg_tracking_code_amd import synth
     shifts = synth.shifts(ring, seed=1234 + rank)
+    pinned = []
     for i in range(ring):
-        ctx.synth_frame(i, w, h, int(shifts[i, 0]), int(shifts[i, 1]), 1234 + rank)
+        ctx.synth_frame(0 if host else i, w, h, int(shifts[i, 0]), int(shifts[i, 1]), 1234 + rank)
+        if host:   # the same frames, parked in pinned host memory
+            import ctypes
+            img = np.ascontiguousarray(ctx.download_level(0, 0))
+            ptr = ctx.host_alloc(w * h)
+            ctypes.memmove(ptr, img.ctypes.data, w * h)
+            pinned.append(ptr)
     ctx.sync()
 
     fp = dict(maxCorners=cfg["max_corners"], **DETECT)
     lk = dict(winSize=cfg["win"], maxLevel=cfg["max_level"], criteria=cfg["criteria"])
-    tracker = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx)
+    tracker = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx,
+                             lookahead=not args.no_lookahead)
     order = ping_pong(ring, K + W)
 
     def barrier():
@@ -170,8 +186,19 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
 
+    def step(i):
+        if not host:
+            # the following frame is resident too: its detection (if it is a detection frame) may start now
+            tracker.push_slot(order[i], wait=False, next_slot=order[i + 1] if i + 1 < W + K else None)
+            return
+        if i + 1 < W + K:   # frame i+1 starts crossing PCIe before frame i is tracked
+            tracker.prefetch_pinned(pinned[order[i + 1]], w)
+        tracker.push_prefetched(wait=False)
+
+    if host:
+        tracker.prefetch_pinned(pinned[order[0]], w)
     for i in range(W):
-        tracker.push_slot(order[i], wait=False)
+        step(i)
     barrier()
     _, tracked0 = tracker.live()
     ctx.prof_reset()
@@ -179,7 +206,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(W, W + K):
-        tracker.push_slot(order[i], wait=False)
+        step(i)
     barrier()
     t1 = time.perf_counter()
     ctx.prof_enable(False)
@@ -211,7 +238,9 @@ def main():
             "config": {"workload": cfg["name"], "width": w, "height": h, "max_corners": cfg["max_corners"],
                        "win": list(cfg["win"]), "maxLevel": cfg["max_level"], "pyramid_images": top + 1,
                        "criteria": list(cfg["criteria"]), "track_len": TRACK_LEN, "detector": DETECT,
-                       "frames_resident": ring, "sharding": "independent segments per rank, no data-path collective"},
+                       "frames_resident": ring,
+                       "source": "pinned host memory, hipMemcpyAsync double-buffered" if host else "HBM-resident",
+                       "sharding": "independent segments per rank, no data-path collective"},
         }
         kern = {}
         lkp = prof.get("lk_fb")
@@ -254,6 +283,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    for ptr in pinned:
+        ctx.host_free(ptr)
     ctx.close()
 
 

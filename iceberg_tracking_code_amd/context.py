@@ -101,6 +101,15 @@ class Context:
     def upload_gray_async(self, slot, pinned_ptr, w, h, stride):
         self._ck(self._lib.icelk_upload_gray_async(self._h, slot, C.c_void_p(pinned_ptr), w, h, stride))
 
+    def host_alloc(self, nbytes):
+        """Pinned host memory for `upload_gray_async` (address as int); release with `host_free`."""
+        p = C.c_void_p()
+        self._ck(self._lib.icelk_host_alloc(C.byref(p), int(nbytes)))
+        return p.value
+
+    def host_free(self, ptr):
+        self._ck(self._lib.icelk_host_free(C.c_void_p(ptr)))
+
     def synth_frame(self, slot, w, h, ux=0, uy=0, seed=1234):
         self._ck(self._lib.icelk_synth_frame(self._h, slot, w, h, int(ux), int(uy), int(seed)))
 

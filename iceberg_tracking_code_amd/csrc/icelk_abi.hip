@@ -59,6 +59,8 @@ struct Ctx {
     // segment state
     float* d_live = nullptr;               // (max_pts,2) current position of every track of the segment
     uint8_t* d_alive = nullptr;            // 1 while the track survives
+    int* d_order = nullptr;                // spatial launch order of the segment's tracks (k_seg_order)
+    bool use_order = true;                 // ICELK_NO_ORDER=1 launches in detector order (A/B measurements)
     unsigned long long* d_tracked = nullptr;   // 64 sharded counters
     unsigned long long* h_seg = nullptr;   // pinned: {alive tracks, features tracked}
     float *d_tracks = nullptr, *d_quality = nullptr, *d_out_tracks = nullptr, *d_out_quality = nullptr;
@@ -205,6 +207,12 @@ static int wait_slot(Ctx* c, int slot)
     return ICELK_OK;
 }
 
+static int mark_used(Ctx* c, int slot)
+{
+    HIPCHK(c, hipEventRecord(c->slots[slot].used, c->stream));
+    return ICELK_OK;
+}
+
 static int begin_frame(Ctx* c, int slot, int w, int h)
 {
     int rc = check_slot(c, slot, false);
@@ -225,6 +233,7 @@ static int ensure_pyramid(Ctx* c, int slot, int top_level)
     int rc = wait_slot(c, slot);
     if (rc) return rc;
     if (top_level + 1 > kMaxLevels) FAIL(c, ICELK_EARG, "maxLevel too large");
+    const bool build = s.levels_built < top_level + 1;
     while (s.levels_built < top_level + 1) {
         const int l = s.levels_built;
         {
@@ -235,7 +244,7 @@ static int ensure_pyramid(Ctx* c, int slot, int top_level)
         if (rc) return rc;
         s.levels_built++;
     }
-    return ICELK_OK;
+    return build ? mark_used(c, slot) : ICELK_OK;
 }
 
 static Pyramid pyramid_of(const Slot& s)
@@ -299,6 +308,8 @@ static void destroy_ctx(Ctx* c)
         if (s.base) hipFree(s.base);
         if (s.ready) hipEventDestroy(s.ready);
         if (s.frame_ev) hipEventDestroy(s.frame_ev);
+        if (s.used) hipEventDestroy(s.used);
+        if (s.det_used) hipEventDestroy(s.det_used);
     }
     if (c->det_stream) hipStreamSynchronize(c->det_stream);
     if (c->det_done) hipEventDestroy(c->det_done);
@@ -309,7 +320,7 @@ static void destroy_ctx(Ctx* c)
     void* ptrs[] = {c->d_bgr, c->d_mask, c->d_p0, c->d_p1, c->d_p0r, c->d_err_f, c->d_err_b, c->d_dist, c->d_corners,
                     c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.max_key, c->D.cand, c->D.cand_count,
                     c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.cell_cand, c->D.state, c->D.undecided,
-                    c->D.acc, c->D.acc_sorted, c->D.acc_count, c->D.blk_count, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->d_live, c->d_alive,
+                    c->D.acc, c->D.acc_sorted, c->D.acc_count, c->D.blk_count, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->d_live, c->d_alive, c->d_order,
                     c->d_tracked, c->d_tracks, c->d_quality,
                     c->d_out_tracks, c->d_out_quality};
     for (void* p : ptrs)
@@ -383,6 +394,7 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
     }
     rc = check_launch(c, "corner candidates");
     if (rc) return rc;
+    HIPCHK(c, hipEventRecord(s.det_used, ds));   // nothing after this launch reads the frame
     DetectJob& J = c->job;
     J.w = w;
     J.h = h;
@@ -512,6 +524,7 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
         B.dist = c->d_dist;
         B.valid = c->d_valid;
         B.seg_alive = c->d_alive;
+        B.order = c->use_order ? c->d_order : nullptr;
         B.seg_xy = c->d_live;
         B.seg_tracks = c->d_tracks;
         B.seg_quality = c->d_quality;
@@ -524,6 +537,8 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
         }
         if (rc) FAIL(c, rc, "unsupported window size");
         rc = check_launch(c, "lk_fb");
+        if (!rc) rc = mark_used(c, slot_prev);
+        if (!rc) rc = mark_used(c, slot_next);
         if (rc) return rc;
     }
     c->seg_vert += 1;
@@ -596,7 +611,9 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         if ((rc = dmalloc(c, &s.base, sb))) return fail(rc);
         s.bytes = sb;
         if (hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.frame_ev, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&s.frame_ev, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.used, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.det_used, hipEventDisableTiming) != hipSuccess) {
             c->err = "hipEventCreate failed";
             return fail(ICELK_EHIP);
         }
@@ -621,11 +638,12 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &D.acc, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.acc_sorted, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, &D.blk_count, candidate_blocks(max_w, max_h) * 4)) ||
         (rc = dmalloc(c, &D.key_hist, 1 << 16)) || (rc = dmalloc(c, &D.prune_key, 1)) || (rc = dmalloc(c, (uint8_t**)&D.sort_tmp, D.sort_tmp_bytes)) ||
-        (rc = dmalloc(c, &c->d_live, 2 * np)) || (rc = dmalloc(c, &c->d_alive, np)) ||
+        (rc = dmalloc(c, &c->d_live, 2 * np)) || (rc = dmalloc(c, &c->d_alive, np)) || (rc = dmalloc(c, &c->d_order, np)) ||
         (rc = dmalloc(c, &c->d_tracked, 64)) || (rc = dmalloc(c, &c->d_tracks, np * kMaxVert * 2)) ||
         (rc = dmalloc(c, &c->d_quality, np * (kMaxVert - 1))) || (rc = dmalloc(c, &c->d_out_tracks, np * kMaxVert * 2)) ||
         (rc = dmalloc(c, &c->d_out_quality, np * (kMaxVert - 1))))
         return fail(rc);
+    c->use_order = getenv("ICELK_NO_ORDER") == nullptr;
     if (hipMemset(c->d_tracked, 0, 64 * 8) != hipSuccess) {
         c->err = "hipMemset failed";
         return fail(ICELK_EHIP);
@@ -688,9 +706,9 @@ int icelk_upload_gray_async(icelk_t* h, int slot, const uint8_t* pinned_host, in
     int rc = begin_frame(c, slot, w, h_);
     if (rc) return rc;
     Slot& s = c->slots[slot];
-    // the copy must not overtake kernels still reading this slot on the compute stream
-    HIPCHK(c, hipEventRecord(s.ready, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, s.ready, 0));
+    // the copy must not overtake the launches that still read this slot (Slot::used / det_used)
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, s.used, 0));
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, s.det_used, 0));
     HIPCHK(c, hipMemcpy2DAsync(s.lv[0].ptr, s.lv[0].pitch, pinned_host, stride, w, h_, hipMemcpyHostToDevice,
                                c->copy_stream));
     HIPCHK(c, hipEventRecord(s.ready, c->copy_stream));
@@ -1044,6 +1062,7 @@ int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n)
     if (rc) return rc;
     if (n > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->det_done, 0));
     launch_seg_init(c->stream, c->d_corners, n, c->d_live, c->d_alive, c->d_tracks, kMaxVert);
+    if (c->use_order) launch_seg_order(c->stream, c->d_corners, n, c->job.w, c->job.h, c->d_order);
     rc = check_launch(c, "seg_init");
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->corners_free, c->stream));

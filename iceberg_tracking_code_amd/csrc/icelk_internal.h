@@ -59,6 +59,10 @@ struct Slot {
     hipEvent_t ready = nullptr;   // upload-complete event (async uploads)
     bool pending = false;
     hipEvent_t frame_ev = nullptr;  // level 0 written (recorded on the compute stream by every ingest call)
+    // last readers of the slot: pyramid/tracker launches on the compute stream, the corner kernel on the
+    // detection stream.  An asynchronous upload into the slot waits for exactly these, not for everything that
+    // happens to be queued, so frame t+1 crosses PCIe while frame t is being tracked.
+    hipEvent_t used = nullptr, det_used = nullptr;
 };
 
 struct ProfEvt {
@@ -86,6 +90,7 @@ struct LKBuffers {
     float* dist;
     uint8_t* valid;
     const int* n_dev;    // optional device-side count (overrides n when non-null)
+    const int* order;    // optional launch order (k_tracks.hip k_seg_order); results do not depend on it
     // Segment mode (icelk_seg_track): the launch itself keeps the track table.  Feature f is track f of the
     // segment; dead tracks (seg_alive[f] == 0) exit at once, survivors of the forward-backward test get their
     // new vertex and distance appended and their position updated in place -- the Python loop of
@@ -152,6 +157,7 @@ void launch_emit_corners(hipStream_t s, const unsigned long long* keys, int n, i
 void launch_seg_init(hipStream_t s, const float* corners, int n, float* xy, uint8_t* alive, float* tracks,
                      int max_vert);
 // {alive tracks, features tracked so far} -> host_out[0..1] (pinned, 64-bit each)
+void launch_seg_order(hipStream_t s, const float* xy, int n, int w, int h, int* order);
 void launch_seg_stats(hipStream_t s, const uint8_t* alive, int n, const unsigned long long* tracked_shards,
                       unsigned long long* host_out);
 // rows of the alive tracks, in track order, packed into out_tracks (n_alive, nvert, 2) / out_quality

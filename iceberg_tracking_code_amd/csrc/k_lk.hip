@@ -281,9 +281,8 @@ template <int PPL, bool FB>
 __global__ __launch_bounds__(64) void k_lk(Pyramid PI, Pyramid PJ, LKBuffers B, int n, LKParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int f = blockIdx.x;
-    const int count = B.n_dev ? *B.n_dev : n;
-    if (f >= count) return;
+    const int f = launch_slot(B, blockIdx.x, B.n_dev ? *B.n_dev : n);
+    if (f < 0) return;
     if (B.seg_alive && !B.seg_alive[f]) return;
     const int lane = threadIdx.x;
     const float p0x = B.p_in[2 * f], p0y = B.p_in[2 * f + 1];
@@ -315,8 +314,8 @@ template <int PPL>
 void launch_ppl(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
                 bool fb, size_t lds)
 {
-    if (fb) hipLaunchKernelGGL((k_lk<PPL, true>), dim3(n), dim3(64), lds, s, I, J, B, n, P);
-    else hipLaunchKernelGGL((k_lk<PPL, false>), dim3(n), dim3(64), lds, s, I, J, B, n, P);
+    if (fb) hipLaunchKernelGGL((k_lk<PPL, true>), dim3(B.order ? (n + 7) & ~7 : n), dim3(64), lds, s, I, J, B, n, P);
+    else hipLaunchKernelGGL((k_lk<PPL, false>), dim3(B.order ? (n + 7) & ~7 : n), dim3(64), lds, s, I, J, B, n, P);
 }
 
 }  // namespace

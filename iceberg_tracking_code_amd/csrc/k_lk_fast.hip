@@ -457,9 +457,8 @@ __global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : 2)) void k_lk_fast
 {
     using C = Cfg<WW, WH>;
     __shared__ uint32_t lds[C::LDS_DW];
-    const int f = blockIdx.x;
-    const int count = B.n_dev ? *B.n_dev : n;
-    if (f >= count) return;
+    const int f = launch_slot(B, blockIdx.x, B.n_dev ? *B.n_dev : n);
+    if (f < 0) return;
     if (B.seg_alive && !B.seg_alive[f]) return;
     const int lane = threadIdx.x;
     uint32_t* ldsI = lds;
@@ -490,8 +489,8 @@ template <int WW, int WH>
 void launch_fast(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
                  bool fb)
 {
-    if (fb) hipLaunchKernelGGL((k_lk_fast<WW, WH, true>), dim3(n), dim3(64), 0, s, I, J, B, n, P);
-    else hipLaunchKernelGGL((k_lk_fast<WW, WH, false>), dim3(n), dim3(64), 0, s, I, J, B, n, P);
+    if (fb) hipLaunchKernelGGL((k_lk_fast<WW, WH, true>), dim3(B.order ? (n + 7) & ~7 : n), dim3(64), 0, s, I, J, B, n, P);
+    else hipLaunchKernelGGL((k_lk_fast<WW, WH, false>), dim3(B.order ? (n + 7) & ~7 : n), dim3(64), 0, s, I, J, B, n, P);
 }
 
 }  // namespace

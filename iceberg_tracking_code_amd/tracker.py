@@ -152,7 +152,7 @@ class SegmentTracker:
     """
 
     def __init__(self, width, height, track_len, feature_params=None, lk_params=None, mask=None, max_pts=1 << 18,
-                 device=0, fb_threshold=REF_FB_THRESHOLD, ctx=None, n_slots=3):
+                 device=0, fb_threshold=REF_FB_THRESHOLD, ctx=None, n_slots=3, lookahead=True):
         self.track_len = int(track_len)
         if self.track_len < 1 or self.track_len > 16:
             raise ValueError("track_len must be in 1..16")
@@ -170,9 +170,14 @@ class SegmentTracker:
         self.seg_first = 0
         self.active = False
         self.n_detected = 0
+        self._prefetched = []     # slots holding frames whose upload was started ahead of time
+        self.lookahead = bool(lookahead)
+        self._det_started = False  # the detection of the coming detection frame is already in flight
 
     # -- frame sources --------------------------------------------------------------------------
     def _next_slot(self):
+        if self._prefetched:
+            raise RuntimeError("prefetched frames are pending; consume them with push_prefetched()")
         return (self.cur + 1) % self.n_slots
 
     def push(self, frame_gray, wait=True):
@@ -195,10 +200,28 @@ class SegmentTracker:
         self.ctx.upload_gray_async(s, pinned_ptr, self.w, self.h, stride)
         return self._step(s, wait)
 
-    def push_slot(self, slot, wait=True):
-        """Use a frame that already sits in `slot` (level 0 resident in HBM); its pyramid is rebuilt."""
+    def prefetch_pinned(self, pinned_ptr, stride):
+        """Start the upload of a FUTURE frame from pinned host memory (BASELINE.json configs[2]: hipMemcpyAsync
+        double buffering).  Frames are consumed in prefetch order by `push_prefetched`; with n_slots slots at
+        most n_slots - 2 uploads may be in flight (previous and current frame stay resident)."""
+        if len(self._prefetched) >= self.n_slots - 2:
+            raise RuntimeError("too many frames in flight for %d slots" % self.n_slots)
+        last = self._prefetched[-1] if self._prefetched else self.cur
+        s = (last + 1) % self.n_slots
+        self.ctx.upload_gray_async(s, pinned_ptr, self.w, self.h, stride)
+        self._prefetched.append(s)
+
+    def push_prefetched(self, wait=True):
+        if not self._prefetched:
+            raise RuntimeError("no prefetched frame")
+        s = self._prefetched.pop(0)
+        return self._step(s, wait, self._prefetched[0] if self._prefetched else None)
+
+    def push_slot(self, slot, wait=True, next_slot=None):
+        """Use a frame that already sits in `slot` (level 0 resident in HBM); its pyramid is rebuilt.
+        `next_slot`: where the following frame already sits, if it does (see `_step`)."""
         self.ctx.drop_pyramid(slot)
-        return self._step(slot, wait)
+        return self._step(slot, wait, next_slot)
 
     def push_synth(self, ux, uy, seed=1234, wait=True):
         s = self._next_slot()
@@ -206,15 +229,26 @@ class SegmentTracker:
         return self._step(s, wait)
 
     # -- the loop body (s1:313-450) -------------------------------------------------------------
-    def _step(self, slot, wait):
+    def _detect_begin(self, slot):
+        self.ctx.seg_detect_begin(slot, self.fp["maxCorners"], self.fp["qualityLevel"], self.fp["minDistance"],
+                                  self.use_mask, self.fp.get("blockSize", 3))
+
+    def _step(self, slot, wait, next_slot=None):
+        """One pass of the loop body.  `next_slot`: slot of the FOLLOWING frame when it is already on its way to
+        the device (prefetched upload, resident ring).  The detector needs nothing but its own frame, so when the
+        following frame is a detection frame its detection is started here, on the detection stream, and runs
+        beside the tracker launches of this step and the next; results are those of the serial order."""
         out = None
         prev = self.cur
         detect = self.counter % self.track_len == 0
-        if detect:
-            # the detector needs this frame only: start it first, on its own stream, so that it runs beside
-            # the tracker launch below (the reference does them back to back, s1:323-326 then s1:437)
-            self.ctx.seg_detect_begin(slot, self.fp["maxCorners"], self.fp["qualityLevel"], self.fp["minDistance"],
-                                      self.use_mask, self.fp.get("blockSize", 3))
+        if detect and not self._det_started:
+            # start it first, on its own stream, so that it runs beside the tracker launch below (the reference
+            # does them back to back, s1:323-326 then s1:437)
+            self._detect_begin(slot)
+        elif (self.lookahead and not detect and next_slot is not None and self.track_len >= 2
+              and (self.counter + 1) % self.track_len == 0):
+            self._detect_begin(next_slot)
+            self._det_started = True
         if self.active:
             self.ctx.seg_track(prev, slot, self.lk["winSize"], self.lk["maxLevel"], self.lk["criteria"],
                                self.lk.get("minEigThreshold", 1e-4), self.fb_threshold, wait=False)
@@ -223,6 +257,7 @@ class SegmentTracker:
                 tracks, quality = self.ctx.seg_read()
                 out = (self.seg_first, tracks, quality)
             self.n_detected = self.ctx.seg_detect_finish(self.fp["maxCorners"])
+            self._det_started = False
             self.active = True
             self.seg_first = self.counter
         self.cur = slot

@@ -104,3 +104,64 @@ def test_pinned_streaming_equals_blocking_upload(synth):
     assert len(a) == len(b) == 3
     for (fa, ta, qa), (fb, tb, qb) in zip(a, b):
         assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb) and len(ta) > 300
+
+
+def test_prefetched_uploads_equal_blocking_upload(synth):
+    """Frame t+1 is put on the copy stream before frame t is tracked (4 slots, per-slot last-use events): the
+    segments must be those of the blocking path."""
+    from iceberg_tracking_code_amd import Context, SegmentTracker
+    w, h, n = 640, 360, 9
+    frames, _ = synth.sequence(w, h, n, seed=21, max_step_px=2.0)
+    fp = dict(maxCorners=400, qualityLevel=0.007, minDistance=10, blockSize=10)
+    lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
+    ref = SegmentTracker(w, h, 2, fp, lk, max_pts=4096)
+    want = [s for s in (ref.push(f) for f in frames) if s is not None]
+    ref.close()
+    trk = SegmentTracker(w, h, 2, fp, lk, max_pts=4096, n_slots=4)
+    ptrs = []
+    for f in frames:   # every frame gets its own pinned buffer: no refill hazards in the test itself
+        p = trk.ctx.host_alloc(w * h)
+        C.memmove(p, f.ctypes.data, w * h)
+        ptrs.append(p)
+    got = []
+    trk.prefetch_pinned(ptrs[0], w)
+    with pytest.raises(RuntimeError):
+        trk.push(frames[0])                     # mixing sources while uploads are pending is refused
+    for i in range(n):
+        if i + 1 < n:
+            trk.prefetch_pinned(ptrs[i + 1], w)
+        s = trk.push_prefetched()
+        if s is not None:
+            got.append(s)
+    with pytest.raises(RuntimeError):
+        trk.push_prefetched()
+    trk.ctx.sync()
+    for p in ptrs:
+        trk.ctx.host_free(p)
+    trk.close()
+    assert len(got) == len(want) == 4
+    for (fa, ta, qa), (fb, tb, qb) in zip(want, got):
+        assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb) and len(ta) > 200
+
+
+def test_launch_order_is_invisible(synth, monkeypatch):
+    """The spatial launch order of a segment's tracks (k_seg_order + XCD dealing) changes which workgroup tracks
+    which feature, never a result: ICELK_NO_ORDER=1 must give identical segments."""
+    from iceberg_tracking_code_amd import SegmentTracker
+    w, h, n = 1030, 770, 5
+    frames, _ = synth.sequence(w, h, n, seed=4, max_step_px=2.5)
+    fp = dict(maxCorners=0, qualityLevel=0.007, minDistance=10, blockSize=10)
+    lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
+
+    def run():
+        trk = SegmentTracker(w, h, 2, fp, lk, max_pts=1 << 15)
+        out = [s for s in (trk.push(f) for f in frames) if s is not None]
+        trk.close()
+        return out
+
+    a = run()
+    monkeypatch.setenv("ICELK_NO_ORDER", "1")
+    b = run()
+    assert len(a) == len(b) == 2
+    for (fa, ta, qa), (fb, tb, qb) in zip(a, b):
+        assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb) and len(ta) > 2000
