@@ -158,7 +158,7 @@ def main():
     if host:
         ring = min(ring, 8)
     max_pts = max(cfg["max_corners"], 1 << 14) if cfg["max_corners"] > 0 else 1 << 18
-    ctx = Context(w, h, n_slots=4 if host else ring, max_pts=max_pts, device=local_rank)
+    ctx = Context(w, h, n_slots=5 if host else ring, max_pts=max_pts, device=local_rank)
     from iceberg_tracking_code_amd import synth
     shifts = synth.shifts(ring, seed=1234 + rank)
     pinned = []
@@ -189,14 +189,16 @@ def main():
     def step(i):
         if not host:
             # the following frame is resident too: its detection (if it is a detection frame) may start now
-            tracker.push_slot(order[i], wait=False, next_slot=order[i + 1] if i + 1 < W + K else None)
+            tracker.push_slot(order[i], wait=False, next_slot=order[i + 1] if i + 1 < W + K else None,
+                              next2_slot=order[i + 2] if i + 2 < W + K else None)
             return
-        if i + 1 < W + K:   # frame i+1 starts crossing PCIe before frame i is tracked
-            tracker.prefetch_pinned(pinned[order[i + 1]], w)
+        if i + 2 < W + K:   # frames i+1, i+2 are crossing PCIe while frame i is tracked
+            tracker.prefetch_pinned(pinned[order[i + 2]], w)
         tracker.push_prefetched(wait=False)
 
     if host:
         tracker.prefetch_pinned(pinned[order[0]], w)
+        tracker.prefetch_pinned(pinned[order[1]], w)
     for i in range(W):
         step(i)
     barrier()

@@ -201,6 +201,9 @@ class Context:
                                             float(minDistance), int(blockSize), C.byref(n)))
         return n.value
 
+    def seg_detect_prepare(self, slot, use_mask=False, blockSize=3):
+        self._ck(self._lib.icelk_seg_detect_prepare(self._h, slot, 1 if use_mask else 0, int(blockSize)))
+
     def seg_detect_begin(self, slot, maxCorners, qualityLevel, minDistance, use_mask=False, blockSize=3):
         self._ck(self._lib.icelk_seg_detect_begin(self._h, slot, 1 if use_mask else 0, int(maxCorners),
                                                   float(qualityLevel), float(minDistance), int(blockSize)))

@@ -55,6 +55,23 @@ struct Ctx {
 
     DetectScratch D{};
     size_t ncell_cap = 0;
+    // Output of the corner kernel (candidate regions, per-tile counts, masked maximum), double buffered: the
+    // candidates of a FUTURE detection frame can be produced (icelk_seg_detect_prepare, on eig_stream) while the
+    // min-distance stage of the current one still reads its own.  D.raw / D.blk_count / D.max_key /
+    // D.src_* always mirror eo[eo_active].
+    struct EigOut {
+        unsigned long long* raw = nullptr;
+        int* blk_count = nullptr;
+        unsigned* max_key = nullptr;
+        int nblk = 0, region = 0;
+        bool valid = false;          // holds the candidates of (slot, gen) for (block_size, use_mask, mask_gen)
+        int slot = -1, block_size = 0, use_mask = 0;
+        unsigned long long gen = 0, mask_gen = 0;
+        hipEvent_t done = nullptr;
+    } eo[2];
+    int eo_active = 0;
+    hipStream_t eig_stream = nullptr;
+    unsigned long long mask_gen = 0;
 
     // segment state
     float* d_live = nullptr;               // (max_pts,2) current position of every track of the segment
@@ -224,6 +241,7 @@ static int begin_frame(Ctx* c, int slot, int w, int h)
     s.h = h;
     layout_levels(s, w, h);
     s.levels_built = 0;
+    s.gen++;
     return ICELK_OK;
 }
 
@@ -312,15 +330,20 @@ static void destroy_ctx(Ctx* c)
         if (s.det_used) hipEventDestroy(s.det_used);
     }
     if (c->det_stream) hipStreamSynchronize(c->det_stream);
+    if (c->eig_stream) hipStreamSynchronize(c->eig_stream);
     if (c->det_done) hipEventDestroy(c->det_done);
     if (c->corners_free) hipEventDestroy(c->corners_free);
     if (c->det_stream) hipStreamDestroy(c->det_stream);
+    if (c->eig_stream) hipStreamDestroy(c->eig_stream);
+    for (auto& e : c->eo)
+        if (e.done) hipEventDestroy(e.done);
     if (c->h_counts) hipHostFree(c->h_counts);
     if (c->h_seg) hipHostFree(c->h_seg);
     void* ptrs[] = {c->d_bgr, c->d_mask, c->d_p0, c->d_p1, c->d_p0r, c->d_err_f, c->d_err_b, c->d_dist, c->d_corners,
-                    c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.max_key, c->D.cand, c->D.cand_count,
+                    c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.cand, c->D.cand_count,
                     c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.cell_cand, c->D.state, c->D.undecided,
-                    c->D.acc, c->D.acc_sorted, c->D.acc_count, c->D.blk_count, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->d_live, c->d_alive, c->d_order,
+                    c->D.acc, c->D.acc_sorted, c->D.acc_count, c->eo[0].raw, c->eo[1].raw, c->eo[0].blk_count, c->eo[1].blk_count,
+                    c->eo[0].max_key, c->eo[1].max_key, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->d_live, c->d_alive, c->d_order,
                     c->d_tracked, c->d_tracks, c->d_quality,
                     c->d_out_tracks, c->d_out_quality};
     for (void* p : ptrs)
@@ -354,6 +377,64 @@ static int fetch_counts(Ctx* c)
     return ICELK_OK;
 }
 
+// make eo[idx] the buffer the detector stages read (and the non-prepared corner kernel writes)
+static void activate_eig_out(Ctx* c, int idx)
+{
+    c->eo_active = idx;
+    const Ctx::EigOut& e = c->eo[idx];
+    c->D.raw = e.raw;
+    c->D.blk_count = e.blk_count;
+    c->D.max_key = e.max_key;
+    c->D.src_nblk = e.nblk;
+    c->D.src_region = e.region;
+}
+
+// Corner candidates of a frame ahead of its detection (fused kernel only; anything else is left to
+// detect_begin).  Runs on eig_stream into the spare buffer; detect_begin adopts it when slot, frame
+// generation, blockSize and mask still match.
+static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
+{
+    int rc = check_slot(c, slot, true);
+    if (rc) return rc;
+    if (!fused_block_size(block_size) || getenv("ICELK_GENERIC_CORNERS")) return ICELK_OK;
+    Slot& s = c->slots[slot];
+    const uint8_t* mask = nullptr;
+    if (use_mask) {
+        if (!c->has_mask) FAIL(c, ICELK_ESTATE, "use_mask set but no mask uploaded");
+        if (c->mask_w != s.w || c->mask_h != s.h) FAIL(c, ICELK_EARG, "mask size differs from the frame");
+        mask = c->d_mask;
+    }
+    Ctx::EigOut& e = c->eo[c->eo_active ^ 1];
+    if (e.valid && e.slot == slot && e.gen == s.gen && e.block_size == block_size && e.use_mask == use_mask &&
+        e.mask_gen == c->mask_gen)
+        return ICELK_OK;   // already there
+    const hipStream_t es = c->eig_stream;
+    HIPCHK(c, hipStreamWaitEvent(es, s.frame_ev, 0));
+    if (s.pending) HIPCHK(c, hipStreamWaitEvent(es, s.ready, 0));
+    HIPCHK(c, hipMemsetAsync(e.max_key, 0, sizeof(unsigned), es));
+    DetectScratch T = c->D;
+    T.raw = e.raw;
+    T.blk_count = e.blk_count;
+    T.max_key = e.max_key;
+    {
+        ProfScope p(c, K_EIG, es);
+        launch_candidates(es, T, s.lv[0], block_size, mask, c->mask_pitch, 1.0, false, nullptr);
+    }
+    rc = check_launch(c, "corner candidates (prepared)");
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(e.done, es));
+    HIPCHK(c, hipEventRecord(s.det_used, es));
+    e.nblk = T.src_nblk;
+    e.region = T.src_region;
+    e.valid = true;
+    e.slot = slot;
+    e.gen = s.gen;
+    e.block_size = block_size;
+    e.use_mask = use_mask;
+    e.mask_gen = c->mask_gen;
+    return ICELK_OK;
+}
+
 static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double quality, double min_distance,
                         int block_size)
 {
@@ -384,17 +465,26 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
     if (s.pending) HIPCHK(c, hipStreamWaitEvent(ds, s.ready, 0));
     HIPCHK(c, hipStreamWaitEvent(ds, c->corners_free, 0));
     const bool generic = getenv("ICELK_GENERIC_CORNERS") != nullptr;
-    {
+    // counters are normally left zeroed by the previous detection (the reset runs after its last kernel,
+    // off the critical path); reset here only the first time or when the cell grid grew
+    const bool need_reset = !c->counters_clean || ncell > c->reset_ncell;
+    Ctx::EigOut& spare = c->eo[c->eo_active ^ 1];
+    const bool prepared = spare.valid && spare.slot == slot && spare.gen == s.gen && spare.block_size == block_size &&
+                          spare.use_mask == use_mask && spare.mask_gen == c->mask_gen && !generic;
+    spare.valid = false;   // adopted below, or stale: either way it is not offered again
+    if (prepared) {
+        if (need_reset) launch_detect_reset(ds, D, (int)ncell, true);   // before the swap: the prepared maximum stays
+        activate_eig_out(c, c->eo_active ^ 1);
+        HIPCHK(c, hipStreamWaitEvent(ds, spare.done, 0));
+    } else {
         ProfScope p(c, K_EIG, ds);
-        // counters are normally left zeroed by the previous detection (the reset runs after its last kernel,
-        // off the critical path); reset here only the first time or when the cell grid grew
-        if (!c->counters_clean || ncell > c->reset_ncell) launch_detect_reset(ds, D, (int)ncell, true);
-        c->counters_clean = false;
+        if (need_reset) launch_detect_reset(ds, D, (int)ncell, true);
         launch_candidates(ds, D, s.lv[0], block_size, mask, c->mask_pitch, quality, generic, nullptr);
+        HIPCHK(c, hipEventRecord(s.det_used, ds));   // nothing after this launch reads the frame
     }
+    c->counters_clean = false;
     rc = check_launch(c, "corner candidates");
     if (rc) return rc;
-    HIPCHK(c, hipEventRecord(s.det_used, ds));   // nothing after this launch reads the frame
     DetectJob& J = c->job;
     J.w = w;
     J.h = h;
@@ -597,6 +687,9 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         create_priority_stream(&c->det_stream) != hipSuccess ||
+        create_priority_stream(&c->eig_stream) != hipSuccess ||
+        hipEventCreateWithFlags(&c->eo[0].done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->eo[1].done, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), 64, hipHostMallocMapped) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->h_seg), 64, hipHostMallocMapped) != hipSuccess ||
         hipEventCreateWithFlags(&c->det_done, hipEventDisableTiming) != hipSuccess ||
@@ -630,13 +723,15 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &c->d_p0, 2 * np)) || (rc = dmalloc(c, &c->d_p1, 2 * np)) || (rc = dmalloc(c, &c->d_p0r, 2 * np)) ||
         (rc = dmalloc(c, &c->d_err_f, np)) || (rc = dmalloc(c, &c->d_err_b, np)) || (rc = dmalloc(c, &c->d_dist, np)) ||
         (rc = dmalloc(c, &c->d_corners, 2 * np)) || (rc = dmalloc(c, &c->d_st_f, np)) || (rc = dmalloc(c, &c->d_st_b, np)) ||
-        (rc = dmalloc(c, &c->d_valid, np)) || (rc = dmalloc(c, &D.eig, npx)) || (rc = dmalloc(c, &D.max_key, 1)) ||
+        (rc = dmalloc(c, &c->d_valid, np)) || (rc = dmalloc(c, &D.eig, npx)) || (rc = dmalloc(c, &c->eo[0].max_key, 1)) || (rc = dmalloc(c, &c->eo[1].max_key, 1)) ||
+        (rc = dmalloc(c, &c->eo[0].raw, (size_t)D.cand_cap)) || (rc = dmalloc(c, &c->eo[1].raw, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.cand, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.cand_count, 1)) ||
         (rc = dmalloc(c, &D.cell_count, c->ncell_cap)) || (rc = dmalloc(c, &D.cell_start, c->ncell_cap)) ||
         (rc = dmalloc(c, &D.cell_fill, c->ncell_cap)) || (rc = dmalloc(c, &D.cell_cand, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.state, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.undecided, 64)) ||
         (rc = dmalloc(c, &D.acc, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.acc_sorted, (size_t)D.cand_cap)) ||
-        (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, &D.blk_count, candidate_blocks(max_w, max_h) * 4)) ||
+        (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, &c->eo[0].blk_count, candidate_blocks(max_w, max_h) * 4)) ||
+        (rc = dmalloc(c, &c->eo[1].blk_count, candidate_blocks(max_w, max_h) * 4)) ||
         (rc = dmalloc(c, &D.key_hist, 1 << 16)) || (rc = dmalloc(c, &D.prune_key, 1)) || (rc = dmalloc(c, (uint8_t**)&D.sort_tmp, D.sort_tmp_bytes)) ||
         (rc = dmalloc(c, &c->d_live, 2 * np)) || (rc = dmalloc(c, &c->d_alive, np)) || (rc = dmalloc(c, &c->d_order, np)) ||
         (rc = dmalloc(c, &c->d_tracked, 64)) || (rc = dmalloc(c, &c->d_tracks, np * kMaxVert * 2)) ||
@@ -644,6 +739,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &c->d_out_quality, np * (kMaxVert - 1))))
         return fail(rc);
     c->use_order = getenv("ICELK_NO_ORDER") == nullptr;
+    activate_eig_out(c, 0);
     if (hipMemset(c->d_tracked, 0, 64 * 8) != hipSuccess) {
         c->err = "hipMemset failed";
         return fail(ICELK_EHIP);
@@ -969,15 +1065,18 @@ int icelk_set_mask(icelk_t* h, const uint8_t* host_mask, int w, int h_, int stri
     HIPCHK(c, hipSetDevice(c->device));
     if (!host_mask) {
         c->has_mask = false;
+        c->mask_gen++;
         return ICELK_OK;
     }
     if (w <= 0 || h_ <= 0 || stride < w) FAIL(c, ICELK_EARG, "bad mask");
     if (w > c->max_w || h_ > c->max_h) FAIL(c, ICELK_ECAP, "mask larger than max_w x max_h");
     HIPCHK(c, hipStreamSynchronize(c->det_stream));
+    HIPCHK(c, hipStreamSynchronize(c->eig_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy2DAsync(c->d_mask, c->mask_pitch, host_mask, stride, w, h_, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_mask = true;
+    c->mask_gen++;
     c->mask_w = w;
     c->mask_h = h_;
     return ICELK_OK;
@@ -1050,6 +1149,15 @@ int icelk_seg_detect_begin(icelk_t* h, int slot, int use_mask, int max_corners, 
     Ctx* c = C(h);
     HIPCHK(c, hipSetDevice(c->device));
     return detect_begin(c, slot, use_mask, max_corners, quality_level, min_distance, block_size);
+}
+
+int icelk_seg_detect_prepare(icelk_t* h, int slot, int use_mask, int block_size)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (block_size <= 0) FAIL(c, ICELK_EARG, "bad detector parameters");
+    return detect_prepare(c, slot, use_mask, block_size);
 }
 
 int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n)

@@ -63,6 +63,7 @@ struct Slot {
     // detection stream.  An asynchronous upload into the slot waits for exactly these, not for everything that
     // happens to be queued, so frame t+1 crosses PCIe while frame t is being tracked.
     hipEvent_t used = nullptr, det_used = nullptr;
+    unsigned long long gen = 0;   // bumped whenever a new frame enters the slot
 };
 
 struct ProfEvt {
@@ -121,6 +122,7 @@ struct DetectScratch {
     int* undecided;        // 1
     unsigned long long* acc;   // accepted keys
     unsigned long long* acc_sorted;
+    unsigned long long* raw;   // candidate regions written by the corner kernel (one of two buffers, see icelk_abi.hip)
     int* acc_count;        // 1
     void* sort_tmp;
     size_t sort_tmp_bytes;
@@ -133,7 +135,7 @@ void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig,
                     int mask_pitch, unsigned* max_key);
 bool fused_block_size(int bs);
 void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, bool full);   // full: before launch_candidates
-// K6+K7: local maxima into per-workgroup regions of D.acc_sorted (stream order, no host sync)
+// K6+K7: local maxima into per-workgroup regions of D.raw (stream order, no host sync)
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
                        int mask_pitch, double quality, bool use_generic, float* eig_out_or_null);
 size_t candidate_capacity(int w, int h);   // keys the region layout needs

@@ -802,7 +802,7 @@ void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig,
 static CandSrc src_of(const DetectScratch& D)
 {
     CandSrc c;
-    c.keys = D.acc_sorted;
+    c.keys = D.raw;
     c.blk_count = D.blk_count;
     c.nblk = D.src_nblk;
     c.region = D.src_region;
@@ -821,11 +821,11 @@ void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, bool full)
                        D.acc_count, D.cand_count, D.max_key, D.key_hist, D.prune_key, full ? 1 : 0);
 }
 
-// Candidate collection (K6+K7) into regions of D.acc_sorted (stream order, no host sync).
+// Candidate collection (K6+K7) into regions of D.raw (stream order, no host sync).
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
                        int mask_pitch, double quality, bool use_generic, float* eig_out_or_null)
 {
-    unsigned long long* raw = D.acc_sorted;
+    unsigned long long* raw = D.raw;
     CandSrc g_src{};
     if (!use_generic && fused_block_size(block_size)) {
         float k0, k1;

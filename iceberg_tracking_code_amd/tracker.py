@@ -215,13 +215,14 @@ class SegmentTracker:
         if not self._prefetched:
             raise RuntimeError("no prefetched frame")
         s = self._prefetched.pop(0)
-        return self._step(s, wait, self._prefetched[0] if self._prefetched else None)
+        q = self._prefetched
+        return self._step(s, wait, q[0] if q else None, q[1] if len(q) > 1 else None)
 
-    def push_slot(self, slot, wait=True, next_slot=None):
+    def push_slot(self, slot, wait=True, next_slot=None, next2_slot=None):
         """Use a frame that already sits in `slot` (level 0 resident in HBM); its pyramid is rebuilt.
-        `next_slot`: where the following frame already sits, if it does (see `_step`)."""
+        `next_slot`, `next2_slot`: where the following two frames already sit, if they do (see `_step`)."""
         self.ctx.drop_pyramid(slot)
-        return self._step(slot, wait, next_slot)
+        return self._step(slot, wait, next_slot, next2_slot)
 
     def push_synth(self, ux, uy, seed=1234, wait=True):
         s = self._next_slot()
@@ -233,20 +234,24 @@ class SegmentTracker:
         self.ctx.seg_detect_begin(slot, self.fp["maxCorners"], self.fp["qualityLevel"], self.fp["minDistance"],
                                   self.use_mask, self.fp.get("blockSize", 3))
 
-    def _step(self, slot, wait, next_slot=None):
-        """One pass of the loop body.  `next_slot`: slot of the FOLLOWING frame when it is already on its way to
-        the device (prefetched upload, resident ring).  The detector needs nothing but its own frame, so when the
-        following frame is a detection frame its detection is started here, on the detection stream, and runs
-        beside the tracker launches of this step and the next; results are those of the serial order."""
+    def _step(self, slot, wait, next_slot=None, next2_slot=None):
+        """One pass of the loop body.  `next_slot` / `next2_slot`: slots of the two FOLLOWING frames when they are
+        already on their way to the device (prefetched uploads, resident ring).  The detector needs nothing but
+        its own frame, so work for a coming detection frame is started early and runs beside the tracker
+        launches of the steps in between: its corner candidates two steps ahead (`seg_detect_prepare`, spare
+        buffer, third stream), its min-distance stage one step ahead.  Results are those of the serial order."""
         out = None
         prev = self.cur
-        detect = self.counter % self.track_len == 0
+        T = self.track_len
+        detect = self.counter % T == 0
+        ahead = self.lookahead and T >= 2
+        if ahead and next2_slot is not None and (self.counter + 2) % T == 0:
+            self.ctx.seg_detect_prepare(next2_slot, self.use_mask, self.fp.get("blockSize", 3))
         if detect and not self._det_started:
             # start it first, on its own stream, so that it runs beside the tracker launch below (the reference
             # does them back to back, s1:323-326 then s1:437)
             self._detect_begin(slot)
-        elif (self.lookahead and not detect and next_slot is not None and self.track_len >= 2
-              and (self.counter + 1) % self.track_len == 0):
+        elif ahead and not detect and next_slot is not None and (self.counter + 1) % T == 0:
             self._detect_begin(next_slot)
             self._det_started = True
         if self.active:

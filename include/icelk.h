@@ -129,6 +129,12 @@ int icelk_seg_detect(icelk_t* h, int slot, int use_mask, int max_corners, double
 int icelk_seg_detect_begin(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level,
                            double min_distance, int block_size);
 int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n);
+/* Optional, ahead of _begin: produce the corner candidates (min-eigenvalue map + non-max test, the part of
+ * s1:437 that depends on nothing but the frame and blockSize) of a frame that is already in `slot`, on a third
+ * stream and into a spare buffer, while an earlier detection is still in its min-distance stage.  A later
+ * _begin for the same slot/frame/blockSize/mask adopts the result; otherwise it is dropped.  Results are
+ * identical either way. */
+int icelk_seg_detect_prepare(icelk_t* h, int slot, int use_mask, int block_size);
 int icelk_seg_track(icelk_t* h, int slot_prev, int slot_next, int win_w, int win_h, int max_level,
                     int crit_type, int max_count, double epsilon, double min_eig_threshold,
                     float fb_threshold, int* out_live);

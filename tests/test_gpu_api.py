@@ -107,8 +107,9 @@ def test_pinned_streaming_equals_blocking_upload(synth):
 
 
 def test_prefetched_uploads_equal_blocking_upload(synth):
-    """Frame t+1 is put on the copy stream before frame t is tracked (4 slots, per-slot last-use events): the
-    segments must be those of the blocking path."""
+    """Frames t+1 and t+2 are put on the copy stream before frame t is tracked (5 slots, per-slot last-use
+    events), which also lets the tracker start detection work one and two steps early (seg_detect_prepare /
+    seg_detect_begin on the look-ahead frames): the segments must be those of the blocking path."""
     from iceberg_tracking_code_amd import Context, SegmentTracker
     w, h, n = 640, 360, 9
     frames, _ = synth.sequence(w, h, n, seed=21, max_step_px=2.0)
@@ -117,7 +118,7 @@ def test_prefetched_uploads_equal_blocking_upload(synth):
     ref = SegmentTracker(w, h, 2, fp, lk, max_pts=4096)
     want = [s for s in (ref.push(f) for f in frames) if s is not None]
     ref.close()
-    trk = SegmentTracker(w, h, 2, fp, lk, max_pts=4096, n_slots=4)
+    trk = SegmentTracker(w, h, 2, fp, lk, max_pts=4096, n_slots=5)
     ptrs = []
     for f in frames:   # every frame gets its own pinned buffer: no refill hazards in the test itself
         p = trk.ctx.host_alloc(w * h)
@@ -125,11 +126,12 @@ def test_prefetched_uploads_equal_blocking_upload(synth):
         ptrs.append(p)
     got = []
     trk.prefetch_pinned(ptrs[0], w)
+    trk.prefetch_pinned(ptrs[1], w)
     with pytest.raises(RuntimeError):
         trk.push(frames[0])                     # mixing sources while uploads are pending is refused
     for i in range(n):
-        if i + 1 < n:
-            trk.prefetch_pinned(ptrs[i + 1], w)
+        if i + 2 < n:
+            trk.prefetch_pinned(ptrs[i + 2], w)
         s = trk.push_prefetched()
         if s is not None:
             got.append(s)
