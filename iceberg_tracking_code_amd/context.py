@@ -201,6 +201,9 @@ class Context:
                                             float(minDistance), int(blockSize), C.byref(n)))
         return n.value
 
+    def build_pyramid_ahead(self, slot, winSize=(21, 21), maxLevel=3):
+        self._ck(self._lib.icelk_build_pyramid_ahead(self._h, slot, winSize[0], winSize[1], maxLevel))
+
     def seg_detect_prepare(self, slot, use_mask=False, blockSize=3):
         self._ck(self._lib.icelk_seg_detect_prepare(self._h, slot, 1 if use_mask else 0, int(blockSize)))
 

@@ -954,6 +954,39 @@ int icelk_build_pyramid(icelk_t* h, int slot, int win_w, int win_h, int max_leve
     return ICELK_OK;
 }
 
+int icelk_build_pyramid_ahead(icelk_t* h, int slot, int win_w, int win_h, int max_level)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = check_slot(c, slot, true);
+    if (rc) return rc;
+    if (win_w <= 2 || win_h <= 2 || max_level < 0) FAIL(c, ICELK_EARG, "bad pyramid parameters");
+    if (max_level > kMaxLevels - 1) max_level = kMaxLevels - 1;
+    Slot& s = c->slots[slot];
+    const int top = pyramid_top_level(s.w, s.h, win_w, win_h, max_level);
+    if (s.levels_built >= top + 1) return ICELK_OK;
+    const hipStream_t cs = c->copy_stream;
+    // level 0 must be there (it may have been written on the compute stream), and launches that still read the
+    // slot's previous pyramid must be through
+    HIPCHK(c, hipStreamWaitEvent(cs, s.frame_ev, 0));
+    if (s.pending) HIPCHK(c, hipStreamWaitEvent(cs, s.ready, 0));
+    HIPCHK(c, hipStreamWaitEvent(cs, s.used, 0));
+    while (s.levels_built < top + 1) {
+        const int l = s.levels_built;
+        {
+            ProfScope p(c, K_PYRDOWN, cs);
+            launch_pyrdown(cs, s.lv[l - 1], s.lv[l]);
+        }
+        rc = check_launch(c, "pyrdown (ahead)");
+        if (rc) return rc;
+        s.levels_built++;
+    }
+    HIPCHK(c, hipEventRecord(s.ready, cs));
+    s.pending = true;
+    return ICELK_OK;
+}
+
 // ---- tracker -----------------------------------------------------------------------------------
 int icelk_pyrlk(icelk_t* h, int prev_slot, int next_slot, const float* prev_xy, float* next_xy, uint8_t* status,
                 float* err, int n, int win_w, int win_h, int max_level, int crit_type, int max_count, double epsilon,

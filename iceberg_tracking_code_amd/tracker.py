@@ -172,6 +172,8 @@ class SegmentTracker:
         self.n_detected = 0
         self._prefetched = []     # slots holding frames whose upload was started ahead of time
         self.lookahead = bool(lookahead)
+        self._pyr_ahead = None    # slot whose pyramid was enqueued ahead of its step
+        self._resident = False    # inside push_slot
         self._det_started = False  # the detection of the coming detection frame is already in flight
 
     # -- frame sources --------------------------------------------------------------------------
@@ -221,8 +223,13 @@ class SegmentTracker:
     def push_slot(self, slot, wait=True, next_slot=None, next2_slot=None):
         """Use a frame that already sits in `slot` (level 0 resident in HBM); its pyramid is rebuilt.
         `next_slot`, `next2_slot`: where the following two frames already sit, if they do (see `_step`)."""
-        self.ctx.drop_pyramid(slot)
-        return self._step(slot, wait, next_slot, next2_slot)
+        if self._pyr_ahead != slot:
+            self.ctx.drop_pyramid(slot)
+        self._resident = True
+        try:
+            return self._step(slot, wait, next_slot, next2_slot)
+        finally:
+            self._resident = False
 
     def push_synth(self, ux, uy, seed=1234, wait=True):
         s = self._next_slot()
@@ -257,6 +264,13 @@ class SegmentTracker:
         if self.active:
             self.ctx.seg_track(prev, slot, self.lk["winSize"], self.lk["maxLevel"], self.lk["criteria"],
                                self.lk.get("minEigThreshold", 1e-4), self.fb_threshold, wait=False)
+        self._pyr_ahead = None
+        if self.lookahead and next_slot is not None:
+            # the pyramid of the following frame, on the copy stream, in the shadow of the tracker launch above
+            if self._resident:
+                self.ctx.drop_pyramid(next_slot)   # a resident ring is rebuilt on every visit
+            self.ctx.build_pyramid_ahead(next_slot, self.lk["winSize"], self.lk["maxLevel"])
+            self._pyr_ahead = next_slot
         if detect:
             if self.counter > 0 and wait:
                 tracks, quality = self.ctx.seg_read()

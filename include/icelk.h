@@ -88,6 +88,10 @@ int icelk_download_level(icelk_t* h, int slot, int level, uint8_t* host, int str
 /* Builds levels 1..L of the slot, L = min(max_level, first level whose successor is <= winSize).
  * *out_levels receives L.  icelk_pyrlk / icelk_track_fb call this themselves when needed. */
 int icelk_build_pyramid(icelk_t* h, int slot, int win_w, int win_h, int max_level, int* out_levels);
+/* The same build enqueued on the handle's copy stream, for a frame that will be tracked LATER: it follows an
+ * icelk_upload_gray_async of the slot in stream order and overlaps whatever the compute stream is doing; the
+ * next call that needs the pyramid waits for it.  Returns at once. */
+int icelk_build_pyramid_ahead(icelk_t* h, int slot, int win_w, int win_h, int max_level);
 
 /* ---- tracker: replaces cv2.calcOpticalFlowPyrLK(img0, img1, p0, None, **lk_params) s1:323,326 - */
 /* next_xy is an input as well when flags has ICELK_FLAG_INITIAL_FLOW.  n == 0 is not an error. */
