@@ -58,6 +58,8 @@ SIGNATURES = {
     "icelk_seg_track_async": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_double, C.c_double, C.c_float]),
     "icelk_seg_live": (C.c_int, [handle_p, i32p, i64p]),
+    "icelk_project_tracks": (C.c_int, [handle_p, f32p, C.c_int, C.c_int, vp, vp, f64p, f64p, f64p, f64p, f64p, u8p]),
+    "icelk_seg_project": (C.c_int, [handle_p, vp, vp, C.c_int, C.c_int, f64p, f64p, f64p, f64p, f64p, u8p, i32p, i32p]),
     "icelk_seg_read": (C.c_int, [handle_p, f32p, f32p, C.c_int, C.c_int, i32p, i32p]),
     "icelk_prof_enable": (C.c_int, [handle_p, C.c_int]),
     "icelk_prof_reset": (C.c_int, [handle_p]),

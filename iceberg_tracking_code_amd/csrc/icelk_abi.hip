@@ -15,7 +15,7 @@ constexpr int kMaxVert = 17;  // vertices per track kept on the device (track_le
 
 static const char* kKernelNames[K_COUNT_] = {
     "bgr2gray", "pyrdown", "lk", "lk_fb", "corner_candidates", "unused5", "unused6", "min_distance", "sort_emit",
-    "compact", "synth",
+    "project_tracks", "synth",
 };
 
 struct DetectJob {
@@ -81,6 +81,10 @@ struct Ctx {
     unsigned long long* d_tracked = nullptr;   // 64 sharded counters
     unsigned long long* h_seg = nullptr;   // pinned: {alive tracks, features tracked}
     float *d_tracks = nullptr, *d_quality = nullptr, *d_out_tracks = nullptr, *d_out_quality = nullptr;
+    // projection epilogue: outputs x, y, u, v, speed (5 planes of proj_cap doubles) + keep bytes, grown on demand
+    double* d_proj = nullptr;
+    uint8_t* d_keep = nullptr;
+    size_t proj_cap = 0;
     int seg_vert = 0, seg_upper = 0;   // vertices so far, tracks of the segment (= corners detected)
     bool seg_active = false;
 
@@ -345,7 +349,7 @@ static void destroy_ctx(Ctx* c)
                     c->D.acc, c->D.acc_sorted, c->D.acc_count, c->eo[0].raw, c->eo[1].raw, c->eo[0].blk_count, c->eo[1].blk_count,
                     c->eo[0].max_key, c->eo[1].max_key, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->d_live, c->d_alive, c->d_order,
                     c->d_tracked, c->d_tracks, c->d_quality,
-                    c->d_out_tracks, c->d_out_quality};
+                    c->d_out_tracks, c->d_out_quality, c->d_proj, c->d_keep};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -1230,6 +1234,90 @@ int icelk_seg_track_async(icelk_t* h, int slot_prev, int slot_next, int win_w, i
     HIPCHK(c, hipSetDevice(c->device));
     return seg_track_core(c, slot_prev, slot_next, win_w, win_h, max_level, crit_type, max_count, epsilon,
                           min_eig_threshold, fb_threshold);
+}
+
+// run the projection kernel over `n` gathered tracks sitting in d_tracks_in and bring the results to the host
+static int project_core(Ctx* c, const float* d_tracks_in, int n, int nv, const icelk_camera_t* cam,
+                        const icelk_utm_filter_t* filt, int host_pitch, double* x, double* y, double* u, double* v,
+                        double* speed, uint8_t* keep)
+{
+    const int m = nv - 1;
+    const size_t need = (size_t)n * (m > 0 ? m : 1);
+    if (need > c->proj_cap) {
+        if (c->d_proj) hipFree(c->d_proj);
+        c->d_proj = nullptr;
+        c->proj_cap = 0;
+        int rc = dmalloc(c, &c->d_proj, 5 * need);
+        if (!rc && !c->d_keep) rc = dmalloc(c, &c->d_keep, (size_t)c->max_pts);   // n <= max_pts always
+        if (rc) return rc;
+        c->proj_cap = need;
+    }
+    double* P[5];
+    for (int k = 0; k < 5; k++) P[k] = c->d_proj + (size_t)k * c->proj_cap;
+    {
+        ProfScope p(c, K_PROJECT);
+        launch_project_tracks(c->stream, d_tracks_in, n, nv, *cam, *filt, P[0], P[1], P[2], P[3], P[4], c->d_keep);
+    }
+    int rc = check_launch(c, "project_tracks");
+    if (rc) return rc;
+    double* H[5] = {x, y, u, v, speed};
+    for (int k = 0; k < 5; k++)
+        if (H[k] && m > 0)
+            HIPCHK(c, hipMemcpy2DAsync(H[k], sizeof(double) * host_pitch, P[k], sizeof(double) * m, sizeof(double) * m, n,
+                                       hipMemcpyDeviceToHost, c->stream));
+    if (keep) HIPCHK(c, hipMemcpyAsync(keep, c->d_keep, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICELK_OK;
+}
+
+static int check_projection_args(Ctx* c, const icelk_camera_t* cam, const icelk_utm_filter_t* filt)
+{
+    if (!cam || !filt) FAIL(c, ICELK_EARG, "camera / filter missing");
+    if (!(filt->interval_s > 0)) FAIL(c, ICELK_EARG, "tracking interval must be positive");
+    return ICELK_OK;
+}
+
+int icelk_project_tracks(icelk_t* h, const float* tracks, int n, int n_vertices, const icelk_camera_t* cam,
+                         const icelk_utm_filter_t* filt, double* x, double* y, double* u, double* v, double* speed,
+                         uint8_t* keep)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = check_projection_args(c, cam, filt);
+    if (rc) return rc;
+    if (n < 0 || n_vertices < 1 || (n > 0 && !tracks)) FAIL(c, ICELK_EARG, "bad track array");
+    if (n > c->max_pts) FAIL(c, ICELK_ECAP, "more tracks than max_pts of icelk_create");
+    if (n_vertices > kMaxVert) FAIL(c, ICELK_ECAP, "more than 17 vertices per track");
+    if (n == 0) return ICELK_OK;
+    HIPCHK(c, hipMemcpyAsync(c->d_out_tracks, tracks, sizeof(float) * 2 * (size_t)n * n_vertices, hipMemcpyHostToDevice,
+                             c->stream));
+    return project_core(c, c->d_out_tracks, n, n_vertices, cam, filt, n_vertices - 1, x, y, u, v, speed, keep);
+}
+
+int icelk_seg_project(icelk_t* h, const icelk_camera_t* cam, const icelk_utm_filter_t* filt, int cap, int max_vectors,
+                      double* x, double* y, double* u, double* v, double* speed, uint8_t* keep, int* out_n,
+                      int* out_vectors)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = check_projection_args(c, cam, filt);
+    if (rc) return rc;
+    if (!c->seg_active) FAIL(c, ICELK_ESTATE, "icelk_seg_detect has not been called");
+    int n = 0;
+    rc = icelk_seg_live(h, &n, nullptr);
+    if (rc) return rc;
+    const int nv = c->seg_vert;
+    if (out_n) *out_n = n;
+    if (out_vectors) *out_vectors = nv - 1;
+    if (n > cap || nv - 1 > max_vectors) FAIL(c, ICELK_ECAP, "host buffers too small");
+    if (n == 0) return ICELK_OK;
+    launch_seg_gather(c->stream, c->d_alive, c->seg_upper, c->d_tracks, c->d_quality, nv, kMaxVert, c->d_out_tracks,
+                      c->d_out_quality);
+    rc = check_launch(c, "seg_gather");
+    if (rc) return rc;
+    return project_core(c, c->d_out_tracks, n, nv, cam, filt, max_vectors, x, y, u, v, speed, keep);
 }
 
 int icelk_seg_live(icelk_t* h, int* out_live, int64_t* out_tracked_total)

@@ -45,7 +45,7 @@ enum KernelId {
     K_CELLS,
     K_SUPPRESS,
     K_EMIT,
-    K_COMPACT,
+    K_PROJECT,
     K_SYNTH,
     K_COUNT_
 };
@@ -159,6 +159,11 @@ void launch_emit_corners(hipStream_t s, const unsigned long long* keys, int n, i
 void launch_seg_init(hipStream_t s, const float* corners, int n, float* xy, uint8_t* alive, float* tracks,
                      int max_vert);
 // {alive tracks, features tracked so far} -> host_out[0..1] (pinned, 64-bit each)
+// projection epilogue (k_utm.hip); the structs are the public ones
+typedef icelk_camera_t UtmCamera;
+typedef icelk_utm_filter_t UtmFilter;
+void launch_project_tracks(hipStream_t s, const float* tracks, int n, int nv, const UtmCamera& cam, const UtmFilter& f,
+                           double* x, double* y, double* u, double* v, double* speed, uint8_t* keep);
 void launch_seg_order(hipStream_t s, const float* xy, int n, int w, int h, int* order);
 void launch_seg_stats(hipStream_t s, const uint8_t* alive, int n, const unsigned long long* tracked_shards,
                       unsigned long long* host_out);

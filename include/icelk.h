@@ -153,6 +153,38 @@ int icelk_seg_track_async(icelk_t* h, int slot_prev, int slot_next, int win_w, i
                           float fb_threshold);
 int icelk_seg_live(icelk_t* h, int* out_live, int64_t* out_tracked_total);
 
+/* ---- projection of finished tracks to map coordinates + plausibility filter (the consumer of the path) --
+ * Replaces the per-track Python loops of s2_cam_to_utm.py:243-347: every vertex is moved to uncropped photo
+ * coordinates (imports/camtools.py:414-421) and projected onto the sea-level plane (Camera.photo_to_utm,
+ * imports/camtools.py:286-332); u, v [m/s] = vertex difference / interval, speed = hypot(u, v); a track is
+ * dropped when mean(speed) < min_speed or max(speed) > max_speed, or -- if max(speed) > speed_threshold -- when
+ * consecutive vectors differ by more than max_speedfactor in speed or max_angle degrees in direction.
+ * float64 throughout, the reference's operation order.  X, U, V are the direction cosines of
+ * camtools.py:300-316, formed by the caller (utm.py does it with numpy, as the reference does). */
+typedef struct icelk_camera {
+    double X[3], U[3], V[3];
+    double sigma;              /* image_width / sensor_width * sigma   (camtools.py:145) */
+    double H, E, N;            /* camera height above the water (tide corrected), easting, northing */
+    double half_w, half_h;     /* pic['width'] / 2.0, pic['height'] / 2.0 of the UNCROPPED photo */
+    double crop_left, crop_top;
+} icelk_camera_t;
+typedef struct icelk_utm_filter {
+    double interval_s;         /* seconds between consecutive vertices (the `_at_{dt}sec_` of the file name) */
+    double max_speed, min_speed, max_speedfactor, max_angle, speed_threshold;   /* s2_cam_to_utm.py:84-88 */
+} icelk_utm_filter_t;
+/* tracks: host (n, n_vertices, 2) float32, the `tracks` array of one .npz (s1:394-395).  x, y, u, v, speed: host
+ * (n, n_vertices-1) float64, x/y = map position of each vector's FIRST vertex (s2:296-297).  keep: n bytes --
+ * 1 kept, 0 dropped, 2 = the reference raises ValueError on this track (max() of an empty list: fewer than two
+ * vectors and faster than speed_threshold).  n <= max_pts, n_vertices <= 17. */
+int icelk_project_tracks(icelk_t* h, const float* tracks, int n, int n_vertices, const icelk_camera_t* cam,
+                         const icelk_utm_filter_t* filt, double* x, double* y, double* u, double* v, double* speed,
+                         uint8_t* keep);
+/* The same for the segment held on the device (icelk_seg_*): gather of the surviving tracks + projection, only
+ * results cross PCIe.  cap = rows of the host buffers, max_vectors = their second dimension. */
+int icelk_seg_project(icelk_t* h, const icelk_camera_t* cam, const icelk_utm_filter_t* filt, int cap, int max_vectors,
+                      double* x, double* y, double* u, double* v, double* speed, uint8_t* keep, int* out_n,
+                      int* out_vectors);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Per-kernel HIP-event timing on the handle's stream (bench.py's roofline leg). */
 int icelk_prof_enable(icelk_t* h, int on);

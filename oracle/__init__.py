@@ -6,10 +6,11 @@ and only as the checker or the timed CPU baseline.  The product
 
 PARITY UNPINNED: the reference's arithmetic for this path lives in OpenCV, which is neither in
 /root/reference nor installed here, and the reference ships no fixtures for it.  See the header
-of icelk_oracle.c.
+of icelk_oracle.c.  The projection epilogue (utm_oracle.c) IS pinned: its arithmetic is the reference's own
+numpy code and tests/golden/utm_golden.npz was produced by running it.
 """
 from .cpu import (  # noqa: F401
     CRIT_COUNT, CRIT_EPS, FLAG_INITIAL_FLOW, FLAG_MIN_EIGENVALS,
     build, lib, set_threads, lk_stats, bgr2gray, pyrdown, pyramid_levels, build_pyramid, scharr,
-    pyrlk, track_fb, min_eig_map, good_features,
+    pyrlk, track_fb, min_eig_map, good_features, project_tracks,
 )

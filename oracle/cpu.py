@@ -22,12 +22,25 @@ _u8p = C.POINTER(C.c_uint8)
 _f32p = C.POINTER(C.c_float)
 _i16p = C.POINTER(C.c_int16)
 _i32p = C.POINTER(C.c_int)
+_f64p = C.POINTER(C.c_double)
+
+
+class UtmCamera(C.Structure):
+    """orc_camera_t (utm_oracle.c): direction cosines as camtools.py:300-316 forms them, plus the scalars."""
+    _fields_ = [("X", C.c_double * 3), ("U", C.c_double * 3), ("V", C.c_double * 3), ("sigma", C.c_double),
+                ("H", C.c_double), ("E", C.c_double), ("N", C.c_double), ("half_w", C.c_double),
+                ("half_h", C.c_double), ("crop_left", C.c_double), ("crop_top", C.c_double)]
+
+
+class UtmFilter(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("interval_s", "max_speed", "min_speed", "max_speedfactor", "max_angle",
+                                          "speed_threshold")]
 
 
 def build(force=False):
     """Compile the C restatement with the committed Makefile (gcc only)."""
-    src = os.path.join(_HERE, "icelk_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("icelk_oracle.c", "utm_oracle.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
@@ -53,6 +66,8 @@ def lib():
         L.orc_min_eig_map.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
         L.orc_good_features.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.c_int, _f32p, C.c_int, _i32p]
+        L.orc_project_tracks.argtypes = [_f32p, C.c_int, C.c_int, C.POINTER(UtmCamera), C.POINTER(UtmFilter), _f64p,
+                                         _f64p, _f64p, _f64p, _f64p, _u8p]
         _lib = L
     return _lib
 
@@ -205,3 +220,24 @@ def good_features(img, maxCorners, qualityLevel, minDistance, mask=None, blockSi
     if n.value == 0:
         return None
     return out[:n.value].reshape(-1, 1, 2).copy()
+
+
+def project_tracks(tracks, cam, filt):
+    """utm_oracle.c: `tracks` (n, nv, 2) f32; `cam` / `filt`: dicts with the fields of UtmCamera / UtmFilter.
+    Returns dict(x, y, u, v, speed: (n, nv-1) f64; keep: (n,) u8 -- 1 kept, 0 dropped, 2 reference raises)."""
+    t = np.ascontiguousarray(tracks, dtype=np.float32)
+    n, nv, two = t.shape
+    assert two == 2
+    c = UtmCamera()
+    for k in ("X", "U", "V"):
+        setattr(c, k, (C.c_double * 3)(*[float(v) for v in cam[k]]))
+    for k in ("sigma", "H", "E", "N", "half_w", "half_h", "crop_left", "crop_top"):
+        setattr(c, k, float(cam[k]))
+    f = UtmFilter(**{k: float(filt[k]) for k, _ in UtmFilter._fields_})
+    m = nv - 1
+    out = {k: np.zeros((n, m), np.float64) for k in ("x", "y", "u", "v", "speed")}
+    out["keep"] = np.zeros(n, np.uint8)
+    _chk(lib().orc_project_tracks(_p(t, _f32p), n, nv, C.byref(c), C.byref(f), _p(out["x"], _f64p),
+                                  _p(out["y"], _f64p), _p(out["u"], _f64p), _p(out["v"], _f64p),
+                                  _p(out["speed"], _f64p), _p(out["keep"], _u8p)))
+    return out
