@@ -49,6 +49,8 @@ SIGNATURES = {
                                       C.c_int, i32p]),
     "icelk_detect_stats": (C.c_int, [handle_p, i32p, i32p]),
     "icelk_seg_detect": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, i32p]),
+    "icelk_set_mask_polygon": (C.c_int, [handle_p, f64p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]),
+    "icelk_download_mask": (C.c_int, [handle_p, u8p, C.c_int, i32p, i32p]),
     "icelk_build_pyramid_ahead": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "icelk_seg_detect_prepare": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int]),
     "icelk_seg_detect_begin": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),

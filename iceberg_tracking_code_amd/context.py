@@ -172,6 +172,19 @@ class Context:
         m = _gray2d(mask, "mask")
         self._ck(self._lib.icelk_set_mask(self._h, _u8(m), m.shape[1], m.shape[0], m.strides[0]))
 
+    def set_mask_polygon(self, poly, crop_left, crop_top, w, h):
+        """The mask of s1:285-291 rasterised on the device from `maskpoly` (camtools.py:184-211)."""
+        p = np.ascontiguousarray(poly, dtype=np.float64).reshape(-1, 2)
+        self._ck(self._lib.icelk_set_mask_polygon(self._h, p.ctypes.data_as(_lib.f64p), len(p), float(crop_left),
+                                                  float(crop_top), int(w), int(h)))
+
+    def download_mask(self):
+        w, h = C.c_int(0), C.c_int(0)
+        self._ck(self._lib.icelk_download_mask(self._h, None, 0, C.byref(w), C.byref(h)))
+        m = np.empty((h.value, w.value), np.uint8)
+        self._ck(self._lib.icelk_download_mask(self._h, _u8(m), w.value, C.byref(w), C.byref(h)))
+        return m
+
     def min_eig_map(self, slot, blockSize=3):
         lvl = self.download_level(slot, 0)
         out = np.empty(lvl.shape, np.float32)

@@ -1119,6 +1119,54 @@ int icelk_set_mask(icelk_t* h, const uint8_t* host_mask, int w, int h_, int stri
     return ICELK_OK;
 }
 
+int icelk_set_mask_polygon(icelk_t* h, const double* poly_xy, int n, double crop_left, double crop_top, int w, int h_)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n < 0 || n > 65536 || (n > 0 && !poly_xy) || w <= 0 || h_ <= 0) FAIL(c, ICELK_EARG, "bad polygon / frame size");
+    if (w > c->max_w || h_ > c->max_h) FAIL(c, ICELK_ECAP, "mask larger than max_w x max_h");
+    // no detection may be reading the old mask
+    HIPCHK(c, hipStreamSynchronize(c->det_stream));
+    HIPCHK(c, hipStreamSynchronize(c->eig_stream));
+    double* d_poly = nullptr;
+    int rc = dmalloc(c, &d_poly, 2 * (size_t)(n > 0 ? n : 1));
+    if (rc) return rc;
+    hipError_t e = n > 0 ? hipMemcpyAsync(d_poly, poly_xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream)
+                         : hipSuccess;
+    if (e == hipSuccess) {
+        launch_polygon_mask(c->stream, d_poly, n, crop_left, crop_top, w, h_, c->d_mask, c->mask_pitch);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_poly);
+    if (e != hipSuccess) {
+        c->err = std::string("polygon mask: ") + hipGetErrorString(e);
+        return ICELK_EHIP;
+    }
+    c->has_mask = true;
+    c->mask_gen++;
+    c->mask_w = w;
+    c->mask_h = h_;
+    return ICELK_OK;
+}
+
+int icelk_download_mask(icelk_t* h, uint8_t* host_mask, int stride, int* w, int* h_)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->has_mask) FAIL(c, ICELK_ESTATE, "no mask set");
+    if (w) *w = c->mask_w;
+    if (h_) *h_ = c->mask_h;
+    if (!host_mask) return ICELK_OK;
+    if (stride < c->mask_w) FAIL(c, ICELK_EARG, "bad host stride");
+    HIPCHK(c, hipMemcpy2DAsync(host_mask, stride, c->d_mask, c->mask_pitch, c->mask_w, c->mask_h, hipMemcpyDeviceToHost,
+                               c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICELK_OK;
+}
+
 int icelk_min_eig_map(icelk_t* h, int slot, int block_size, float* host_out, int stride_elems)
 {
     if (!h) return ICELK_EARG;

@@ -164,6 +164,8 @@ typedef icelk_camera_t UtmCamera;
 typedef icelk_utm_filter_t UtmFilter;
 void launch_project_tracks(hipStream_t s, const float* tracks, int n, int nv, const UtmCamera& cam, const UtmFilter& f,
                            double* x, double* y, double* u, double* v, double* speed, uint8_t* keep);
+void launch_polygon_mask(hipStream_t s, const double* poly, int n, double crop_left, double crop_top, int w, int h,
+                         uint8_t* mask, int pitch);
 void launch_seg_order(hipStream_t s, const float* xy, int n, int w, int h, int* order);
 void launch_seg_stats(hipStream_t s, const uint8_t* alive, int n, const unsigned long long* tracked_shards,
                       unsigned long long* host_out);

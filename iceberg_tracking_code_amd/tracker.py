@@ -152,7 +152,7 @@ class SegmentTracker:
     """
 
     def __init__(self, width, height, track_len, feature_params=None, lk_params=None, mask=None, max_pts=1 << 18,
-                 device=0, fb_threshold=REF_FB_THRESHOLD, ctx=None, n_slots=3, lookahead=True):
+                 device=0, fb_threshold=REF_FB_THRESHOLD, ctx=None, n_slots=3, lookahead=True, mask_polygon=None):
         self.track_len = int(track_len)
         if self.track_len < 1 or self.track_len > 16:
             raise ValueError("track_len must be in 1..16")
@@ -162,8 +162,12 @@ class SegmentTracker:
         self.w, self.h = width, height
         self.ctx = ctx if ctx is not None else Context(width, height, n_slots=n_slots, max_pts=max_pts, device=device)
         self.n_slots = self.ctx.n_slots
-        self.use_mask = mask is not None
-        if self.use_mask:
+        self.use_mask = mask is not None or mask_polygon is not None
+        if mask_polygon is not None:
+            # (maskpoly, cropleft, croptop): the mask of s1:285-291 rasterised on the device (camtools.py:184-211)
+            poly, crop_left, crop_top = mask_polygon
+            self.ctx.set_mask_polygon(poly, crop_left, crop_top, width, height)
+        elif mask is not None:
             self.ctx.set_mask(mask)
         self.counter = 0          # frames consumed
         self.cur = -1             # slot of the newest frame

@@ -110,6 +110,13 @@ int icelk_track_fb(icelk_t* h, int slot0, int slot1, const float* p0, int n, int
 /* ---- detector: replaces cv2.goodFeaturesToTrack(frame_gray, mask=mask, **feature_params) s1:437 */
 /* Mask (s1:285-294) is uploaded once and reused; NULL clears it. */
 int icelk_set_mask(icelk_t* h, const uint8_t* host_mask, int w, int h_, int stride);
+/* The mask of s1:285-291 built on the device from the digitised water polygon: poly_xy = n (x, y) pairs on the
+ * UNCROPPED photo (`maskpoly`, camtools.py:165); the polygon is shifted by the crop offsets and every pixel centre of
+ * the w x h_ frame is tested as Camera.mask_meshgrid does (camtools.py:184-211, matplotlib's contains_points rule,
+ * radius 0); inside = 255.  n <= 65536. */
+int icelk_set_mask_polygon(icelk_t* h, const double* poly_xy, int n, double crop_left, double crop_top, int w, int h_);
+/* Copy the current mask to the host (parity / inspection). */
+int icelk_download_mask(icelk_t* h, uint8_t* host_mask, int stride, int* w, int* h_);
 /* cornerMinEigenVal map of the slot (debug / parity). */
 int icelk_min_eig_map(icelk_t* h, int slot, int block_size, float* host_out, int stride_elems);
 /* Shi-Tomasi corners in response order.  max_corners <= 0 = unlimited (up to max_pts).

@@ -39,7 +39,7 @@ class UtmFilter(C.Structure):
 
 def build(force=False):
     """Compile the C restatement with the committed Makefile (gcc only)."""
-    srcs = [os.path.join(_HERE, f) for f in ("icelk_oracle.c", "utm_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("icelk_oracle.c", "utm_oracle.c", "mask_oracle.c")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
@@ -68,6 +68,7 @@ def lib():
                                         C.c_double, C.c_int, _f32p, C.c_int, _i32p]
         L.orc_project_tracks.argtypes = [_f32p, C.c_int, C.c_int, C.POINTER(UtmCamera), C.POINTER(UtmFilter), _f64p,
                                          _f64p, _f64p, _f64p, _f64p, _u8p]
+        L.orc_polygon_mask.argtypes = [_f64p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _u8p, C.c_int]
         _lib = L
     return _lib
 
@@ -241,3 +242,11 @@ def project_tracks(tracks, cam, filt):
                                   _p(out["y"], _f64p), _p(out["u"], _f64p), _p(out["v"], _f64p),
                                   _p(out["speed"], _f64p), _p(out["keep"], _u8p)))
     return out
+
+
+def polygon_mask(poly, crop_left, crop_top, w, h):
+    """mask_oracle.c: polygon (n, 2) on the uncropped photo -> (h, w) u8 mask (255 inside) of the cropped frame."""
+    p = np.ascontiguousarray(poly, dtype=np.float64).reshape(-1, 2)
+    m = np.zeros((h, w), np.uint8)
+    _chk(lib().orc_polygon_mask(_p(p, _f64p), len(p), float(crop_left), float(crop_top), w, h, _p(m, _u8p), w))
+    return m
