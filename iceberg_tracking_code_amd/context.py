@@ -85,11 +85,20 @@ class Context:
         a = _gray2d(img)
         self._ck(self._lib.icelk_upload_gray(self._h, slot, _u8(a), a.shape[1], a.shape[0], a.strides[0]))
 
-    def upload_bgr(self, slot, img, variant=GRAY_CV3):
+    def upload_bgr(self, slot, img, variant=GRAY_CV3, crop=None):
+        """3-channel frame -> gray in `slot` (s1:310-311).  `crop` = (left, top, right, bottom) pixels to drop, the
+        box `Camera.crop_image` cuts (camtools.py:213-231): only the kept region crosses PCIe, straight out of the
+        decoded frame (the reference's lossy JPEG re-save of the crop, s1:272, has no counterpart)."""
         a = np.asarray(img)
         if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
             raise ValueError("expected HxWx3 uint8 image")
-        a = np.ascontiguousarray(a)
+        if crop is not None:
+            left, top, right, bottom = (int(v) for v in crop)
+            if min(left, top, right, bottom) < 0 or left + right >= a.shape[1] or top + bottom >= a.shape[0]:
+                raise ValueError("crop box leaves no image")
+            a = a[top:a.shape[0] - bottom, left:a.shape[1] - right]
+        if a.strides[2] != 1 or a.strides[1] != 3 or a.strides[0] < 3 * a.shape[1]:
+            a = np.ascontiguousarray(a)   # rows must be dense; a row pitch (cropped view) is fine as it is
         self._ck(self._lib.icelk_upload_bgr(self._h, slot, _u8(a), a.shape[1], a.shape[0], a.strides[0], variant))
 
     def set_gray_device(self, slot, dev_ptr, w, h, stride):

@@ -345,7 +345,7 @@ static void destroy_ctx(Ctx* c)
     if (c->h_seg) hipHostFree(c->h_seg);
     void* ptrs[] = {c->d_bgr, c->d_mask, c->d_p0, c->d_p1, c->d_p0r, c->d_err_f, c->d_err_b, c->d_dist, c->d_corners,
                     c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.cand, c->D.cand_count,
-                    c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.cell_cand, c->D.state, c->D.undecided,
+                    c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.chunk_tot, c->D.cell_cand, c->D.state, c->D.undecided,
                     c->D.acc, c->D.acc_sorted, c->D.acc_count, c->eo[0].raw, c->eo[1].raw, c->eo[0].blk_count, c->eo[1].blk_count,
                     c->eo[0].max_key, c->eo[1].max_key, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->d_live, c->d_alive, c->d_order,
                     c->d_tracked, c->d_tracks, c->d_quality,
@@ -731,7 +731,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &c->eo[0].raw, (size_t)D.cand_cap)) || (rc = dmalloc(c, &c->eo[1].raw, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.cand, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.cand_count, 1)) ||
         (rc = dmalloc(c, &D.cell_count, c->ncell_cap)) || (rc = dmalloc(c, &D.cell_start, c->ncell_cap)) ||
-        (rc = dmalloc(c, &D.cell_fill, c->ncell_cap)) || (rc = dmalloc(c, &D.cell_cand, (size_t)D.cand_cap)) ||
+        (rc = dmalloc(c, &D.cell_fill, c->ncell_cap)) || (rc = dmalloc(c, &D.chunk_tot, (c->ncell_cap / 2048 + 2) * 32)) || (rc = dmalloc(c, &D.cell_cand, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.state, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.undecided, 64)) ||
         (rc = dmalloc(c, &D.acc, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.acc_sorted, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, &c->eo[0].blk_count, candidate_blocks(max_w, max_h) * 4)) ||

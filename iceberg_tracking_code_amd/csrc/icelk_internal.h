@@ -117,6 +117,7 @@ struct DetectScratch {
     int* cell_count;       // grid cells + 1
     int* cell_start;       // grid cells + 1
     int* cell_fill;        // grid cells
+    int* chunk_tot;        // candidates per 2048 cells (offsets of the scan's workgroups)
     unsigned long long* cell_cand;  // candidates grouped by cell
     uint8_t* state;        // per grouped candidate: 0 undecided, 1 accepted, 2 rejected
     int* undecided;        // 1

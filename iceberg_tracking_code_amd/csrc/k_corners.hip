@@ -461,21 +461,51 @@ __global__ __launch_bounds__(256) void k_nms_collect(const float* __restrict__ e
 
 // ------------------------------------------------------------------------------------------------
 // K8 helpers.
+// Every kernel of the min-distance stage is launched as ONE-WAVE workgroups (CT = 64 threads) with at most 8 KB of
+// LDS and no more than 128 VGPRs: that is the footprint of a single k_lk_fast wave, so while a tracker launch
+// owns the chip (it holds every VGPR) such a workgroup fits into the hole any retiring tracker wave leaves and
+// the stage progresses beside it; wider workgroups wait for the tracker's tail (tools/ubench/corun.hip:
+// 64 threads / 4 KB LDS 30-60 us beside a register-saturating kernel, >= 128 threads or 16 KB 250-340 us).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cell_count(CandSrc src, const unsigned* __restrict__ max_key, double quality,
-                                                    const unsigned* __restrict__ prune_key, int w, int cell, int gw,
-                                                    int* __restrict__ cell_count)
+constexpr int CT = 64;
+constexpr int SCAN_CHUNK = 2048;   // cells per workgroup of k_scan; k_cell_count also keeps per-chunk totals
+// The chunk totals are hot atomic targets: one per 128-byte line (atomics on one line serialise in its L2 channel,
+// ~90 per us), and a wave adds its contributions to a chunk with one atomic.
+constexpr int CHUNK_TOT_STRIDE = 32;
+
+__device__ __forceinline__ void chunk_add(int* __restrict__ chunk_tot, bool active, int chunk)
+{
+    unsigned long long pending = __ballot(active);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int c = __shfl(chunk, leader);
+        const unsigned long long same = __ballot(active && chunk == c) & pending;
+        if ((int)threadIdx.x == leader) atomicAdd(&chunk_tot[c * CHUNK_TOT_STRIDE], __popcll(same));
+        pending &= ~same;
+    }
+}
+
+__global__ __launch_bounds__(CT) void k_cell_count(CandSrc src, const unsigned* __restrict__ max_key, double quality,
+                                                   const unsigned* __restrict__ prune_key, int w, int cell, int gw,
+                                                   int* __restrict__ cell_count, int* __restrict__ chunk_tot)
 {
     const float thr = threshold_of(max_key, quality);
     const unsigned pk = *prune_key;
     for (int b = blockIdx.x; b < src.nblk; b += gridDim.x) {
         const int cnt = src.blk_count[b];
-        for (int i = threadIdx.x; i < cnt; i += 256) {
-            const unsigned long long key = src.keys[(size_t)b * src.region + i];
-            if ((unsigned)(key >> 32) < pk || !(key_to_float((unsigned)(key >> 32)) > thr)) continue;
-            const unsigned idx = (unsigned)key;
-            const int y = (int)(idx >> 16), x = (int)(idx & 0xffffu);
-            atomicAdd(&cell_count[(y / cell) * gw + (x / cell)], 1);
+        for (int i0 = 0; i0 < cnt; i0 += CT) {
+            const int i = i0 + threadIdx.x;
+            bool keep = false;
+            int c = 0;
+            if (i < cnt) {
+                const unsigned long long key = src.keys[(size_t)b * src.region + i];
+                keep = (unsigned)(key >> 32) >= pk && key_to_float((unsigned)(key >> 32)) > thr;
+                const unsigned idx = (unsigned)key;
+                const int y = (int)(idx >> 16), x = (int)(idx & 0xffffu);
+                c = (y / cell) * gw + (x / cell);
+            }
+            if (keep) atomicAdd(&cell_count[c], 1);
+            chunk_add(chunk_tot, keep, c / SCAN_CHUNK);
         }
     }
 }
@@ -486,121 +516,110 @@ __global__ __launch_bounds__(256) void k_cell_count(CandSrc src, const unsigned*
 // candidates can never appear in the output and need not be binned, relaxed or sorted.  K is found from a
 // 16384-bin histogram of the response key (its top 14 bits); the host checks "accepted >= maxCorners" at its
 // one synchronisation point and reruns unpruned otherwise.
-constexpr int KEY_SHIFT = 18;                 // bin = key >> 18: sign, exponent and 5 mantissa bits
-constexpr int KEY_BINS = 1 << (32 - KEY_SHIFT);
+constexpr int KEY_SHIFT = 18;                 // bin width: sign, exponent and 5 mantissa bits of the key
+constexpr int KEY_BINS = 2048;                // bins counted DOWN from the bin of the maximum: 64 octaves
 // Responses cluster in a few hundred bins, so a global-memory histogram would serialise on a handful of L2
-// atomic addresses: every workgroup histograms into LDS and flushes its non-empty bins.
-__global__ __launch_bounds__(256) void k_key_hist(CandSrc src, const unsigned* __restrict__ max_key, double quality,
-                                                  unsigned* __restrict__ hist)
+// atomic addresses: every workgroup histograms into LDS (8 KB) and flushes its non-empty bins.
+__device__ __forceinline__ int key_bin(unsigned key, unsigned max_key)
+{
+    const int b = (int)(max_key >> KEY_SHIFT) - (int)(key >> KEY_SHIFT);
+    return b < 0 ? 0 : (b >= KEY_BINS ? KEY_BINS - 1 : b);
+}
+
+__global__ __launch_bounds__(CT) void k_key_hist(CandSrc src, const unsigned* __restrict__ max_key, double quality,
+                                                 unsigned* __restrict__ hist)
 {
     __shared__ unsigned lh[KEY_BINS];
-    for (int i = threadIdx.x; i < KEY_BINS; i += 256) lh[i] = 0;
+    for (int i = threadIdx.x; i < KEY_BINS; i += CT) lh[i] = 0;
     __syncthreads();
     const float thr = threshold_of(max_key, quality);
+    const unsigned mk = *max_key;
     for (int b = blockIdx.x; b < src.nblk; b += gridDim.x) {
         const int cnt = src.blk_count[b];
-        for (int i = threadIdx.x; i < cnt; i += 256) {
+        for (int i = threadIdx.x; i < cnt; i += CT) {
             const unsigned k = (unsigned)(src.keys[(size_t)b * src.region + i] >> 32);
-            if (key_to_float(k) > thr) atomicAdd(&lh[k >> KEY_SHIFT], 1u);
+            if (key_to_float(k) > thr) atomicAdd(&lh[key_bin(k, mk)], 1u);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < KEY_BINS; i += 256) {
+    for (int i = threadIdx.x; i < KEY_BINS; i += CT) {
         const unsigned v = lh[i];
         if (v) atomicAdd(&hist[i], v);
     }
 }
 
-// prune_key = lowest key of the highest bins that together hold >= want candidates (0 = keep everything)
-__global__ __launch_bounds__(1024) void k_key_select(const unsigned* __restrict__ hist, unsigned want,
-                                                     unsigned* __restrict__ prune_key)
+// prune_key = lowest key of the strongest bins that together hold >= want candidates (0 = keep everything).
+// One wave; lane l owns bins [32 l, 32 l + 32), bin 0 being the strongest.
+__global__ __launch_bounds__(CT) void k_key_select(const unsigned* __restrict__ hist, unsigned want,
+                                                   const unsigned* __restrict__ max_key,
+                                                   unsigned* __restrict__ prune_key)
 {
-    __shared__ unsigned part[1024];
-    const int tid = threadIdx.x;
-    constexpr int PER = KEY_BINS / 1024;
+    constexpr int PER = KEY_BINS / CT;
+    const int lane = threadIdx.x;
     unsigned s = 0;
-    for (int i = 0; i < PER; i++) s += hist[tid * PER + i];
-    part[tid] = s;
-    __syncthreads();
-    // suffix sums over threads (thread 1023 owns the strongest bins)
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned v = tid + o < 1024 ? part[tid + o] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    for (int i = 0; i < PER; i++) s += hist[lane * PER + i];
+    unsigned incl = s;   // candidates in this lane's bins and all stronger ones
+#pragma unroll
+    for (int o = 1; o < CT; o <<= 1) {
+        const unsigned v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
     }
-    const unsigned above = tid + 1 < 1024 ? part[tid + 1] : 0u;   // candidates in stronger threads' bins
-    if (tid == 0 && part[0] < want) *prune_key = 0u;
-    if (above < want && part[tid] >= want) {
+    const unsigned total = __shfl(incl, CT - 1);
+    if (lane == 0 && total < want) *prune_key = 0u;
+    const unsigned above = incl - s;
+    if (above < want && incl >= want) {
         unsigned run = above;
-        for (int i = PER - 1; i >= 0; i--) {
-            run += hist[tid * PER + i];
+        for (int i = 0; i < PER; i++) {
+            run += hist[lane * PER + i];
             if (run >= want) {
-                *prune_key = (unsigned)(tid * PER + i) << KEY_SHIFT;
+                const int bin = lane * PER + i;   // keep bins 0..bin
+                const int top = (int)(*max_key >> KEY_SHIFT);
+                // the last bin also collects everything weaker: keeping it means keeping all
+                *prune_key = (bin >= KEY_BINS - 1 || top - bin <= 0) ? 0u : (unsigned)(top - bin) << KEY_SHIFT;
                 break;
             }
         }
     }
 }
 
-// exclusive scan, 4096 elements per workgroup: each workgroup first sums everything before its chunk
-// (the count array is L2-resident), then scans its own chunk.  start[n] = total.
-constexpr int SCAN_CHUNK = 4096;
-__device__ __forceinline__ int block_sum_1024(int v, int* sm)
+// exclusive scan of the cell counts, SCAN_CHUNK cells per one-wave workgroup: the offset of a chunk is the sum of the
+// chunk totals before it (kept by k_cell_count), inside the chunk 8 rounds of 4 cells per lane.  start[n] = total.
+__global__ __launch_bounds__(CT) void k_scan(const int* __restrict__ count, const int* __restrict__ chunk_tot,
+                                             int* __restrict__ start, int n)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    const int wave = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sm[wave] = v;
-    __syncthreads();
-    int t = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) t += sm[i];
-    return t;
-}
-
-__global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ count, int* __restrict__ start, int n)
-{
-    __shared__ int sm[16];
-    __shared__ int wave_tot[16];
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     const int lo = blockIdx.x * SCAN_CHUNK;
-    int pre = 0;
-    for (int i = tid; i < lo; i += 1024) pre += count[i];
-    pre = block_sum_1024(pre, sm);
-    // own chunk: 4 consecutive elements per thread
-    int c[4], s = 0;
+    int run = 0;
+    for (int c = lane; c < (int)blockIdx.x; c += CT) run += chunk_tot[c * CHUNK_TOT_STRIDE];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int i = lo + 4 * tid + k;
-        c[k] = i < n ? count[i] : 0;
-        s += c[k];
-    }
-    // inclusive scan of s across the workgroup
-    int inc = s;
-    const int lane = tid & 63, wave = tid >> 6;
+    for (int o = 32; o >= 1; o >>= 1) run += __shfl_xor(run, o);
+    for (int r = 0; r < SCAN_CHUNK / (4 * CT); r++) {
+        const int i0 = lo + r * 4 * CT + 4 * lane;
+        int c[4], s = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(inc, o);
-        if (lane >= o) inc += v;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    int wbase = 0;
-    for (int i = 0; i < wave; i++) wbase += wave_tot[i];
-    int run = pre + wbase + inc - s;
+        for (int k = 0; k < 4; k++) {
+            c[k] = i0 + k < n ? count[i0 + k] : 0;
+            s += c[k];
+        }
+        int inc = s;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int i = lo + 4 * tid + k;
-        if (i < n) start[i] = run;
-        run += c[k];
-        if (i == n - 1) start[n] = run;
+        for (int o = 1; o < CT; o <<= 1) {
+            const int v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        int at = run + inc - s;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < n) start[i0 + k] = at;
+            at += c[k];
+            if (i0 + k == n - 1) start[n] = at;
+        }
+        run += __shfl(inc, CT - 1);
     }
-    if (n == 0 && blockIdx.x == 0 && tid == 0) start[0] = 0;
+    if (n == 0 && blockIdx.x == 0 && lane == 0) start[0] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_cell_fill(CandSrc src, const unsigned* __restrict__ max_key, double quality,
+__global__ __launch_bounds__(CT) void k_cell_fill(CandSrc src, const unsigned* __restrict__ max_key, double quality,
                                                    const unsigned* __restrict__ prune_key, int w, int cell, int gw,
                                                    const int* __restrict__ cell_start, int* __restrict__ cell_fill,
                                                    unsigned long long* __restrict__ cell_cand,
@@ -610,7 +629,7 @@ __global__ __launch_bounds__(256) void k_cell_fill(CandSrc src, const unsigned* 
     const unsigned pk = *prune_key;
     for (int b = blockIdx.x; b < src.nblk; b += gridDim.x) {
         const int cnt = src.blk_count[b];
-        for (int i = threadIdx.x; i < cnt; i += 256) {
+        for (int i = threadIdx.x; i < cnt; i += CT) {
             const unsigned long long key = src.keys[(size_t)b * src.region + i];
             if ((unsigned)(key >> 32) < pk || !(key_to_float((unsigned)(key >> 32)) > thr)) continue;
             const unsigned idx = (unsigned)key;
@@ -631,15 +650,15 @@ __global__ __launch_bounds__(256) void k_cell_fill(CandSrc src, const unsigned* 
 // launch r, and launch r+1 picks them up (it returns at once when that count is zero).
 constexpr int SUP_K = 24;
 constexpr int SUP_SPINS = 48;
-__global__ __launch_bounds__(256) void k_suppress(const unsigned long long* __restrict__ cell_cand,
+__global__ __launch_bounds__(CT) void k_suppress(const unsigned long long* __restrict__ cell_cand,
                                                   const int* __restrict__ n_ptr, int cell, int gw, int gh,
                                                   const int* __restrict__ cell_start, uint8_t* state, double md2,
                                                   int* __restrict__ launch_counters, int r)
 {
-    __shared__ int blockers[SUP_K * 256];
+    __shared__ int blockers[SUP_K * CT];
     if (r > 0 && launch_counters[r - 1] == 0) return;
     const int n = *n_ptr;
-    int* mine = blockers + threadIdx.x;   // entry q at mine[q * 256]: conflict-free
+    int* mine = blockers + threadIdx.x;   // entry q at mine[q * CT]: conflict-free
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (__atomic_load_n(&state[i], __ATOMIC_RELAXED)) continue;
         const unsigned long long key = cell_cand[i];
@@ -661,7 +680,7 @@ __global__ __launch_bounds__(256) void k_suppress(const unsigned long long* __re
                 const uint8_t sj = __atomic_load_n(&state[j], __ATOMIC_RELAXED);
                 if (sj == 1) { rejected = true; break; }
                 if (sj == 0) {
-                    if (cnt < SUP_K) mine[256 * cnt++] = j;
+                    if (cnt < SUP_K) mine[CT * cnt++] = j;
                     else overflow = true;
                 }
             }
@@ -673,10 +692,10 @@ __global__ __launch_bounds__(256) void k_suppress(const unsigned long long* __re
             __builtin_amdgcn_s_sleep(8);
             int k = 0;
             for (int q = 0; q < cnt; q++) {
-                const int j = mine[256 * q];
+                const int j = mine[CT * q];
                 const uint8_t sj = __atomic_load_n(&state[j], __ATOMIC_RELAXED);
                 if (sj == 1) { rejected = true; break; }
-                if (sj == 0) mine[256 * k++] = j;
+                if (sj == 0) mine[CT * k++] = j;
             }
             cnt = k;
             if (rejected) { __atomic_store_n(&state[i], (uint8_t)2, __ATOMIC_RELAXED); decided = true; }
@@ -688,7 +707,7 @@ __global__ __launch_bounds__(256) void k_suppress(const unsigned long long* __re
 
 // zero every counter a detection uses, in one launch (each hipMemsetAsync is a ~5 us kernel of its own)
 __global__ void k_detect_reset(int* __restrict__ cell_count, int* __restrict__ cell_fill, int ncell,
-                               int* __restrict__ undecided, int* __restrict__ acc_count,
+                               int* __restrict__ chunk_tot, int* __restrict__ undecided, int* __restrict__ acc_count,
                                int* __restrict__ cand_count, unsigned* __restrict__ max_key,
                                unsigned* __restrict__ key_hist, unsigned* __restrict__ prune_key, int full)
 {
@@ -696,6 +715,7 @@ __global__ void k_detect_reset(int* __restrict__ cell_count, int* __restrict__ c
     for (int i = i0; i <= ncell; i += gridDim.x * blockDim.x) {
         cell_count[i] = 0;
         if (i < ncell) cell_fill[i] = 0;
+        if (i % SCAN_CHUNK == 0) chunk_tot[(i / SCAN_CHUNK) * CHUNK_TOT_STRIDE] = 0;
     }
     if (full)
         for (int i = i0; i < KEY_BINS; i += gridDim.x * blockDim.x) key_hist[i] = 0;
@@ -708,7 +728,7 @@ __global__ void k_detect_reset(int* __restrict__ cell_count, int* __restrict__ c
     }
 }
 
-__global__ __launch_bounds__(256) void k_gather_accepted(const unsigned long long* __restrict__ cell_cand,
+__global__ __launch_bounds__(CT) void k_gather_accepted(const unsigned long long* __restrict__ cell_cand,
                                                          const int* __restrict__ n_ptr,
                                                          const uint8_t* __restrict__ state,
                                                          unsigned long long* __restrict__ acc,
@@ -716,7 +736,7 @@ __global__ __launch_bounds__(256) void k_gather_accepted(const unsigned long lon
 {
     __shared__ int s_cnt, s_base;
     const int n = *n_ptr;
-    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+    for (int i0 = blockIdx.x * CT; i0 < n; i0 += gridDim.x * CT) {
         const int i = i0 + threadIdx.x;
         const bool keep = i < n && state[i] == 1;
         block_append(keep, keep ? cell_cand[i] : 0ull, acc, acc_count, &s_cnt, &s_base);
@@ -814,10 +834,10 @@ static CandSrc src_of(const DetectScratch& D)
 // what a re-run of the min-distance stage on the same candidates needs.
 void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, bool full)
 {
-    int blocks = (ncell + 256) / 256;
-    if (full && blocks < KEY_BINS / 256) blocks = KEY_BINS / 256;
-    if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(k_detect_reset, dim3(blocks), dim3(256), 0, s, D.cell_count, D.cell_fill, ncell, D.undecided,
+    int blocks = (ncell + CT) / CT;
+    if (full && blocks < KEY_BINS / CT) blocks = KEY_BINS / CT;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_detect_reset, dim3(blocks), dim3(CT), 0, s, D.cell_count, D.cell_fill, ncell, D.chunk_tot, D.undecided,
                        D.acc_count, D.cand_count, D.max_key, D.key_hist, D.prune_key, full ? 1 : 0);
 }
 
@@ -870,13 +890,13 @@ static void suppress_launches(hipStream_t s, DetectScratch& D, int w, int h, dou
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     const double md2 = min_distance * min_distance;
     for (int r = 0; r < kSuppressLaunches; r++)
-        hipLaunchKernelGGL(k_suppress, dim3(1024), dim3(256), 0, s, D.cell_cand, D.cell_start + gw * gh, cell, gw, gh,
+        hipLaunchKernelGGL(k_suppress, dim3(4096), dim3(CT), 0, s, D.cell_cand, D.cell_start + gw * gh, cell, gw, gh,
                            D.cell_start, D.state, md2, D.undecided, r);
 }
 
 static void gather_launch(hipStream_t s, DetectScratch& D, int ncell)
 {
-    hipLaunchKernelGGL(k_gather_accepted, dim3(256), dim3(256), 0, s, D.cell_cand, D.cell_start + ncell, D.state, D.acc,
+    hipLaunchKernelGGL(k_gather_accepted, dim3(1024), dim3(CT), 0, s, D.cell_cand, D.cell_start + ncell, D.state, D.acc,
                        D.acc_count);
 }
 
@@ -887,14 +907,14 @@ void launch_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double m
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     const int ncell = gw * gh;
     if (prune_want > 0) {
-        hipLaunchKernelGGL(k_key_hist, dim3(128), dim3(256), 0, s, src_of(D), D.max_key, quality, D.key_hist);
-        hipLaunchKernelGGL(k_key_select, dim3(1), dim3(1024), 0, s, D.key_hist, (unsigned)prune_want, D.prune_key);
+        hipLaunchKernelGGL(k_key_hist, dim3(256), dim3(CT), 0, s, src_of(D), D.max_key, quality, D.key_hist);
+        hipLaunchKernelGGL(k_key_select, dim3(1), dim3(CT), 0, s, D.key_hist, (unsigned)prune_want, D.max_key, D.prune_key);
     }
-    hipLaunchKernelGGL(k_cell_count, dim3(1024), dim3(256), 0, s, src_of(D), D.max_key, quality, D.prune_key, w, cell, gw,
-                       D.cell_count);
-    hipLaunchKernelGGL(k_scan, dim3((ncell + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(1024), 0, s, D.cell_count,
+    hipLaunchKernelGGL(k_cell_count, dim3(4096), dim3(CT), 0, s, src_of(D), D.max_key, quality, D.prune_key, w, cell, gw,
+                       D.cell_count, D.chunk_tot);
+    hipLaunchKernelGGL(k_scan, dim3((ncell + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(CT), 0, s, D.cell_count, D.chunk_tot,
                        D.cell_start, ncell);
-    hipLaunchKernelGGL(k_cell_fill, dim3(1024), dim3(256), 0, s, src_of(D), D.max_key, quality, D.prune_key, w, cell, gw,
+    hipLaunchKernelGGL(k_cell_fill, dim3(4096), dim3(CT), 0, s, src_of(D), D.max_key, quality, D.prune_key, w, cell, gw,
                        D.cell_start, D.cell_fill, D.cell_cand, D.state);
     suppress_launches(s, D, w, h, min_distance);
     gather_launch(s, D, ncell);
@@ -916,7 +936,7 @@ int suppress_launch_count() { return kSuppressLaunches; }
 void launch_emit_corners(hipStream_t s, const unsigned long long* keys, int n, int w, float* xy)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_emit, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, w, xy);
+    hipLaunchKernelGGL(k_emit, dim3((n + CT - 1) / CT), dim3(CT), 0, s, keys, n, w, xy);
 }
 
 }  // namespace icelk

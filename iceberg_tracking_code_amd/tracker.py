@@ -191,9 +191,10 @@ class SegmentTracker:
         self.ctx.upload_gray(s, frame_gray)
         return self._step(s, wait)
 
-    def push_bgr(self, frame, wait=True, variant=3):
+    def push_bgr(self, frame, wait=True, variant=3, crop=None):
+        """`crop` = (left, top, right, bottom): the box of camtools.py:213-231, cut during the upload."""
         s = self._next_slot()
-        self.ctx.upload_bgr(s, frame, variant)
+        self.ctx.upload_bgr(s, frame, variant, crop)
         return self._step(s, wait)
 
     def push_device(self, dev_ptr, stride, wait=True):

@@ -167,3 +167,20 @@ def test_launch_order_is_invisible(synth, monkeypatch):
     assert len(a) == len(b) == 2
     for (fa, ta, qa), (fb, tb, qb) in zip(a, b):
         assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb) and len(ta) > 2000
+
+
+def test_crop_during_upload_equals_cropping_first(orc, synth):
+    """push_bgr(frame, crop=box) (row-pitched upload of the kept region only) == cropping on the host first; the gray
+    image is the oracle's cvtColor of the cropped array (s1:310-311 on the box of camtools.py:213-231)."""
+    from iceberg_tracking_code_amd import Context
+    rgb = synth.rgb_from_gray_seeded(701, 503, 40, -30, 11)
+    box = (37, 101, 14, 5)                                        # left, top, right, bottom
+    cropped = np.ascontiguousarray(rgb[101:503 - 5, 37:701 - 14])
+    c = Context(701, 503, n_slots=2, max_pts=1024)
+    c.upload_bgr(0, rgb, 3, crop=box)
+    c.upload_bgr(1, cropped, 3)
+    a, b = c.download_level(0, 0), c.download_level(1, 0)
+    with pytest.raises(ValueError):
+        c.upload_bgr(0, rgb, 3, crop=(400, 0, 301, 0))
+    c.close()
+    assert a.shape == (503 - 106, 701 - 51) and np.array_equal(a, b) and np.array_equal(a, orc.bgr2gray(cropped, 3))
