@@ -74,13 +74,24 @@ struct Ctx {
     unsigned long long mask_gen = 0;
 
     // segment state
-    float* d_live = nullptr;               // (max_pts,2) current position of every track of the segment
-    uint8_t* d_alive = nullptr;            // 1 while the track survives
-    int* d_order = nullptr;                // spatial launch order of the segment's tracks (k_seg_order)
+    // Segment state, two sets: while the tracker launch of a detection frame still extends the closing segment in
+    // one set, the new segment is initialised in the other (on the detection stream, right after the corners are
+    // emitted) -- the next tracker launch does not have to wait for an initialisation queued behind its predecessor.
+    struct SegBuf {
+        float* live = nullptr;      // (max_pts,2) current position of every track of the segment
+        uint8_t* alive = nullptr;   // 1 while the track survives
+        int* order = nullptr;       // spatial launch order of the segment's tracks (k_seg_order)
+        float* tracks = nullptr;    // [track][kMaxVert][2]
+        float* quality = nullptr;   // [track][kMaxVert-1]
+        hipEvent_t used = nullptr;  // last launch on the compute stream that touches this set
+    } sb[2];
+    int sb_cur = 0;
+    hipEvent_t seg_ready = nullptr;   // the current set has been initialised (detection stream)
+    bool seg_ready_pending = false;   // ... and the compute stream has not been told to wait for it yet
     bool use_order = true;                 // ICELK_NO_ORDER=1 launches in detector order (A/B measurements)
     unsigned long long* d_tracked = nullptr;   // 64 sharded counters
     unsigned long long* h_seg = nullptr;   // pinned: {alive tracks, features tracked}
-    float *d_tracks = nullptr, *d_quality = nullptr, *d_out_tracks = nullptr, *d_out_quality = nullptr;
+    float *d_out_tracks = nullptr, *d_out_quality = nullptr;
     // projection epilogue: outputs x, y, u, v, speed (5 planes of proj_cap doubles) + keep bytes, grown on demand
     double* d_proj = nullptr;
     uint8_t* d_keep = nullptr;
@@ -339,6 +350,9 @@ static void destroy_ctx(Ctx* c)
     if (c->corners_free) hipEventDestroy(c->corners_free);
     if (c->det_stream) hipStreamDestroy(c->det_stream);
     if (c->eig_stream) hipStreamDestroy(c->eig_stream);
+    if (c->seg_ready) hipEventDestroy(c->seg_ready);
+    for (auto& b : c->sb)
+        if (b.used) hipEventDestroy(b.used);
     for (auto& e : c->eo)
         if (e.done) hipEventDestroy(e.done);
     if (c->h_counts) hipHostFree(c->h_counts);
@@ -347,8 +361,8 @@ static void destroy_ctx(Ctx* c)
                     c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.cand, c->D.cand_count,
                     c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.chunk_tot, c->D.cell_cand, c->D.state, c->D.undecided,
                     c->D.acc, c->D.acc_sorted, c->D.acc_count, c->eo[0].raw, c->eo[1].raw, c->eo[0].blk_count, c->eo[1].blk_count,
-                    c->eo[0].max_key, c->eo[1].max_key, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->d_live, c->d_alive, c->d_order,
-                    c->d_tracked, c->d_tracks, c->d_quality,
+                    c->eo[0].max_key, c->eo[1].max_key, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->sb[0].live, c->sb[1].live, c->sb[0].alive, c->sb[1].alive, c->sb[0].order,
+                    c->sb[1].order, c->sb[0].tracks, c->sb[1].tracks, c->sb[0].quality, c->sb[1].quality, c->d_tracked,
                     c->d_out_tracks, c->d_out_quality, c->d_proj, c->d_keep};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -587,6 +601,16 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
     return detect_finish(c, max_corners, cap, n_out);
 }
 
+// the compute stream must see the current segment set initialised (detection stream) before it touches it
+static int seg_wait(Ctx* c)
+{
+    if (c->seg_ready_pending) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->seg_ready, 0));
+        c->seg_ready_pending = false;
+    }
+    return ICELK_OK;
+}
+
 // shared by icelk_seg_track / icelk_seg_track_async
 static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int win_h, int max_level, int crit_type,
                           int max_count, double epsilon, double min_eig_threshold, float fb_threshold)
@@ -606,9 +630,12 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
     rc = ensure_pyramid(c, slot_prev, P.top_level);
     if (!rc) rc = ensure_pyramid(c, slot_next, P.top_level);
     if (rc) return rc;
+    rc = seg_wait(c);
+    if (rc) return rc;
+    Ctx::SegBuf& S = c->sb[c->sb_cur];
     if (c->seg_upper > 0) {
         LKBuffers B{};
-        B.p_in = c->d_live;
+        B.p_in = S.live;
         B.p_fwd = c->d_p1;
         B.st_fwd = c->d_st_f;
         B.err_fwd = c->d_err_f;
@@ -617,11 +644,11 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
         B.err_bwd = c->d_err_b;
         B.dist = c->d_dist;
         B.valid = c->d_valid;
-        B.seg_alive = c->d_alive;
-        B.order = c->use_order ? c->d_order : nullptr;
-        B.seg_xy = c->d_live;
-        B.seg_tracks = c->d_tracks;
-        B.seg_quality = c->d_quality;
+        B.seg_alive = S.alive;
+        B.order = c->use_order ? S.order : nullptr;
+        B.seg_xy = S.live;
+        B.seg_tracks = S.tracks;
+        B.seg_quality = S.quality;
         B.seg_vert = c->seg_vert;
         B.seg_max_vert = kMaxVert;
         B.seg_tracked = c->d_tracked;
@@ -634,6 +661,7 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
         if (!rc) rc = mark_used(c, slot_prev);
         if (!rc) rc = mark_used(c, slot_next);
         if (rc) return rc;
+        HIPCHK(c, hipEventRecord(S.used, c->stream));
     }
     c->seg_vert += 1;
     return ICELK_OK;
@@ -692,6 +720,9 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         create_priority_stream(&c->det_stream) != hipSuccess ||
         create_priority_stream(&c->eig_stream) != hipSuccess ||
+        hipEventCreateWithFlags(&c->seg_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->sb[0].used, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->sb[1].used, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->eo[0].done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->eo[1].done, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), 64, hipHostMallocMapped) != hipSuccess ||
@@ -737,9 +768,11 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, &c->eo[0].blk_count, candidate_blocks(max_w, max_h) * 4)) ||
         (rc = dmalloc(c, &c->eo[1].blk_count, candidate_blocks(max_w, max_h) * 4)) ||
         (rc = dmalloc(c, &D.key_hist, 1 << 16)) || (rc = dmalloc(c, &D.prune_key, 1)) || (rc = dmalloc(c, (uint8_t**)&D.sort_tmp, D.sort_tmp_bytes)) ||
-        (rc = dmalloc(c, &c->d_live, 2 * np)) || (rc = dmalloc(c, &c->d_alive, np)) || (rc = dmalloc(c, &c->d_order, np)) ||
-        (rc = dmalloc(c, &c->d_tracked, 64)) || (rc = dmalloc(c, &c->d_tracks, np * kMaxVert * 2)) ||
-        (rc = dmalloc(c, &c->d_quality, np * (kMaxVert - 1))) || (rc = dmalloc(c, &c->d_out_tracks, np * kMaxVert * 2)) ||
+        (rc = dmalloc(c, &c->sb[0].live, 2 * np)) || (rc = dmalloc(c, &c->sb[0].alive, np)) || (rc = dmalloc(c, &c->sb[0].order, np)) ||
+        (rc = dmalloc(c, &c->sb[1].live, 2 * np)) || (rc = dmalloc(c, &c->sb[1].alive, np)) || (rc = dmalloc(c, &c->sb[1].order, np)) ||
+        (rc = dmalloc(c, &c->sb[0].tracks, np * kMaxVert * 2)) || (rc = dmalloc(c, &c->sb[1].tracks, np * kMaxVert * 2)) ||
+        (rc = dmalloc(c, &c->sb[0].quality, np * (kMaxVert - 1))) || (rc = dmalloc(c, &c->sb[1].quality, np * (kMaxVert - 1))) ||
+        (rc = dmalloc(c, &c->d_tracked, 64)) || (rc = dmalloc(c, &c->d_out_tracks, np * kMaxVert * 2)) ||
         (rc = dmalloc(c, &c->d_out_quality, np * (kMaxVert - 1))))
         return fail(rc);
     c->use_order = getenv("ICELK_NO_ORDER") == nullptr;
@@ -1253,12 +1286,19 @@ int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n)
     int n = 0;
     int rc = detect_finish(c, max_corners, c->max_pts, &n);
     if (rc) return rc;
-    if (n > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->det_done, 0));
-    launch_seg_init(c->stream, c->d_corners, n, c->d_live, c->d_alive, c->d_tracks, kMaxVert);
-    if (c->use_order) launch_seg_order(c->stream, c->d_corners, n, c->job.w, c->job.h, c->d_order);
+    // the new segment goes into the other set, on the detection stream right behind the corner list; launches
+    // that still touch that set (the segment before the closing one) must be through
+    Ctx::SegBuf& nb = c->sb[c->sb_cur ^ 1];
+    const hipStream_t ds = c->det_stream;
+    HIPCHK(c, hipStreamWaitEvent(ds, nb.used, 0));
+    launch_seg_init(ds, c->d_corners, n, nb.live, nb.alive, nb.tracks, kMaxVert);
+    if (c->use_order) launch_seg_order(ds, c->d_corners, n, c->job.w, c->job.h, nb.order);
     rc = check_launch(c, "seg_init");
     if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->corners_free, c->stream));
+    HIPCHK(c, hipEventRecord(c->corners_free, ds));
+    HIPCHK(c, hipEventRecord(c->seg_ready, ds));
+    c->sb_cur ^= 1;
+    c->seg_ready_pending = true;
     c->seg_vert = 1;
     c->seg_upper = n;
     c->seg_active = true;
@@ -1361,7 +1401,7 @@ int icelk_seg_project(icelk_t* h, const icelk_camera_t* cam, const icelk_utm_fil
     if (out_vectors) *out_vectors = nv - 1;
     if (n > cap || nv - 1 > max_vectors) FAIL(c, ICELK_ECAP, "host buffers too small");
     if (n == 0) return ICELK_OK;
-    launch_seg_gather(c->stream, c->d_alive, c->seg_upper, c->d_tracks, c->d_quality, nv, kMaxVert, c->d_out_tracks,
+    launch_seg_gather(c->stream, c->sb[c->sb_cur].alive, c->seg_upper, c->sb[c->sb_cur].tracks, c->sb[c->sb_cur].quality, nv, kMaxVert, c->d_out_tracks,
                       c->d_out_quality);
     rc = check_launch(c, "seg_gather");
     if (rc) return rc;
@@ -1374,7 +1414,9 @@ int icelk_seg_live(icelk_t* h, int* out_live, int64_t* out_tracked_total)
     Ctx* c = C(h);
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->seg_active) FAIL(c, ICELK_ESTATE, "icelk_seg_detect has not been called");
-    launch_seg_stats(c->stream, c->d_alive, c->seg_upper, c->d_tracked, c->h_seg);
+    int rcw = seg_wait(c);
+    if (rcw) return rcw;
+    launch_seg_stats(c->stream, c->sb[c->sb_cur].alive, c->seg_upper, c->d_tracked, c->h_seg);
     int rc0 = check_launch(c, "seg_stats");
     if (rc0) return rc0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1409,7 +1451,7 @@ int icelk_seg_read(icelk_t* h, float* tracks, float* quality, int cap, int max_v
     if (!tracks && !quality) return ICELK_OK;
     if (n > cap || nv > max_vertices) FAIL(c, ICELK_ECAP, "host track buffers too small");
     if (n == 0) return ICELK_OK;
-    launch_seg_gather(c->stream, c->d_alive, c->seg_upper, c->d_tracks, c->d_quality, nv, kMaxVert, c->d_out_tracks,
+    launch_seg_gather(c->stream, c->sb[c->sb_cur].alive, c->seg_upper, c->sb[c->sb_cur].tracks, c->sb[c->sb_cur].quality, nv, kMaxVert, c->d_out_tracks,
                       c->d_out_quality);
     rc = check_launch(c, "seg_gather");
     if (rc) return rc;
