@@ -646,6 +646,11 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
         B.valid = c->d_valid;
         B.seg_alive = S.alive;
         B.order = c->use_order ? S.order : nullptr;
+        // Dealing the sorted sequence to the XCDs pays while neighbouring windows barely overlap (C2: 244 -> 233 us);
+        // with dense features every XCD would work on one spot of the frame at a time and its L2 channels
+        // serialise (REF: 2 060 us walking the table linearly, 2 680 us dealt, 2 230 us unsorted)
+        const double overlap = (double)(win_w + 12) * (win_h + 12) * c->seg_upper / ((double)s0.w * s0.h);
+        B.order_plain = overlap >= 2.0 ? 1 : 0;
         B.seg_xy = S.live;
         B.seg_tracks = S.tracks;
         B.seg_quality = S.quality;

@@ -92,6 +92,7 @@ struct LKBuffers {
     uint8_t* valid;
     const int* n_dev;    // optional device-side count (overrides n when non-null)
     const int* order;    // optional launch order (k_tracks.hip k_seg_order); results do not depend on it
+    int order_plain;     // walk the order table linearly instead of dealing it to the XCDs (dense features)
     // Segment mode (icelk_seg_track): the launch itself keeps the track table.  Feature f is track f of the
     // segment; dead tracks (seg_alive[f] == 0) exit at once, survivors of the forward-backward test get their
     // new vertex and distance appended and their position updated in place -- the Python loop of

@@ -90,10 +90,12 @@ __device__ __forceinline__ long long wave_sum_exact(int v)
 // Workgroup -> feature.  Without an order table workgroup b tracks feature b.  With one, the table is a
 // spatially sorted sequence of features and workgroup b takes entry (b % 8) * ceil(count / 8) + b / 8:
 // workgroups are dispatched round-robin over the 8 XCDs, so each XCD (own L2) walks one contiguous eighth of
-// the sequence.  -1 = nothing to do; the grid must hold 8 * ceil(count / 8) workgroups.
+// the sequence.  With order_plain the table is walked linearly (consecutive workgroups = neighbouring features on
+// DIFFERENT XCDs).  -1 = nothing to do; the grid must hold 8 * ceil(count / 8) workgroups.
 __device__ __forceinline__ int launch_slot(const LKBuffers& B, int b, int count)
 {
     if (!B.order) return b < count ? b : -1;
+    if (B.order_plain) return b < count ? B.order[b] : -1;
     const int chunk = (count + 7) >> 3, j = b >> 3;
     const int idx = (b & 7) * chunk + j;
     return (j < chunk && idx < count) ? B.order[idx] : -1;

@@ -106,7 +106,8 @@ def test_pinned_streaming_equals_blocking_upload(synth):
         assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb) and len(ta) > 300
 
 
-def test_prefetched_uploads_equal_blocking_upload(synth):
+@pytest.mark.parametrize("track_len", [1, 2, 3])
+def test_prefetched_uploads_equal_blocking_upload(synth, track_len):
     """Frames t+1 and t+2 are put on the copy stream before frame t is tracked (5 slots, per-slot last-use
     events), which also lets the tracker start detection work one and two steps early (seg_detect_prepare /
     seg_detect_begin on the look-ahead frames): the segments must be those of the blocking path."""
@@ -115,10 +116,10 @@ def test_prefetched_uploads_equal_blocking_upload(synth):
     frames, _ = synth.sequence(w, h, n, seed=21, max_step_px=2.0)
     fp = dict(maxCorners=400, qualityLevel=0.007, minDistance=10, blockSize=10)
     lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
-    ref = SegmentTracker(w, h, 2, fp, lk, max_pts=4096)
+    ref = SegmentTracker(w, h, track_len, fp, lk, max_pts=4096, lookahead=False)
     want = [s for s in (ref.push(f) for f in frames) if s is not None]
     ref.close()
-    trk = SegmentTracker(w, h, 2, fp, lk, max_pts=4096, n_slots=5)
+    trk = SegmentTracker(w, h, track_len, fp, lk, max_pts=4096, n_slots=5)
     ptrs = []
     for f in frames:   # every frame gets its own pinned buffer: no refill hazards in the test itself
         p = trk.ctx.host_alloc(w * h)
@@ -141,9 +142,10 @@ def test_prefetched_uploads_equal_blocking_upload(synth):
     for p in ptrs:
         trk.ctx.host_free(p)
     trk.close()
-    assert len(got) == len(want) == 4
+    assert len(got) == len(want) == (n - 1) // track_len
     for (fa, ta, qa), (fb, tb, qb) in zip(want, got):
         assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb) and len(ta) > 200
+        assert ta.shape[1] == track_len + 1
 
 
 def test_launch_order_is_invisible(synth, monkeypatch):
