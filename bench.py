@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--ring", type=int, default=24, help="distinct frames resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="leave out the per-kernel HIP events (and with them the roofline object): shows what they cost")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="start a detection only when its frame is pushed (A/B of the cross-step overlap)")
     ap.add_argument("--source", default="hbm", choices=("hbm", "host"),
@@ -204,7 +206,7 @@ def main():
     barrier()
     _, tracked0 = tracker.live()
     ctx.prof_reset()
-    ctx.prof_enable(True)
+    ctx.prof_enable(not args.no_kernel_timing)
     barrier()
     t0 = time.perf_counter()
     for i in range(W, W + K):
