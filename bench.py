@@ -15,7 +15,7 @@ of images is in it either (the PCIe-inclusive rate is in DESIGN.md).
 
 Multi-GPU: every rank runs its own shard of independent segments (weak scaling, no data-path collective);
 the only collective is the final RCCL all-gather of the per-rank feature counts (BASELINE.json
-north_star).  rank 0 prints ONE JSON line.
+north_star); barriers and the max over ranks of the elapsed time go over gloo.  rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -137,6 +137,12 @@ def main():
                          "pinned host memory, uploads double-buffered against the tracker (BASELINE.json configs[2])")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: gloo / RCCL print banners to file descriptor 1, so everything but that
+    # line is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,11 +150,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    # Control plane (barriers, max of the elapsed time) over gloo; the RCCL communicator is created only for the one
+    # collective of the path, the final gather of the feature counts, AFTER the timed region: a handle already keeps
+    # four HIP streams busy and a fifth queue on the device costs 25-35 %.
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ICELK_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from iceberg_tracking_code_amd import Context, SegmentTracker
 
@@ -224,10 +234,11 @@ def main():
     tracked_all = [tracked]
     if dist is not None:
         from iceberg_tracking_code_amd import sharding
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tracked_all = [int(v) for v in sharding.gather_counts([tracked], dist, device="cuda")]
+        rccl = dist.new_group(backend="nccl")     # RCCL over xGMI
+        tracked_all = [int(v) for v in sharding.gather_counts([tracked], dist, device="cuda", group=rccl)]
 
     if rank == 0:
         top = top_level_of(w, h, cfg["win"], cfg["max_level"])
@@ -283,7 +294,7 @@ def main():
                 pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -32,25 +32,26 @@ def frame_block(n_frames, track_len, rank, world):
     return s0 * track_len, s1 * track_len + 1
 
 
-def gather_counts(local_counts, dist=None, device=None):
+def gather_counts(local_counts, dist=None, device=None, group=None):
     """All ranks' per-segment track counts, concatenated in rank order (int64 numpy array).
 
-    `dist` is torch.distributed (initialised) or None for a single process.  Blocks are padded to the largest
-    block so that one all_gather suffices; messages are a few hundred bytes, i.e. latency bound on any fabric.
+    `dist` is torch.distributed (initialised) or None for a single process; `group` selects the process group
+    (e.g. an RCCL group created beside a gloo control group).  Blocks are padded to the largest block so that one
+    all_gather suffices; messages are a few hundred bytes, i.e. latency bound on any fabric.
     """
     local = np.asarray(local_counts, np.int64).ravel()
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and group is None):
         return local.copy()
     import torch
     world = dist.get_world_size()
     n = torch.tensor([local.size], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
+    dist.all_gather(sizes, n, group=group)
     sizes = [int(s.item()) for s in sizes]
     pad = max(max(sizes), 1)
     mine = torch.zeros(pad, dtype=torch.int64, device=device)
     if local.size:
         mine[:local.size] = torch.from_numpy(local).to(mine.device)
     parts = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine)
+    dist.all_gather(parts, mine, group=group)
     return np.concatenate([p[:k].cpu().numpy() for p, k in zip(parts, sizes)]) if sum(sizes) else np.zeros(0, np.int64)
