@@ -13,6 +13,7 @@ from .context import (Context, DEFAULT_CRITERIA, GRAY_CV3, GRAY_CV4, OPTFLOW_LK_
 from .tracker import (LucasKanade, REF_FB_THRESHOLD, REF_FEATURE_PARAMS, REF_LK_PARAMS, SegmentTracker,  # noqa: F401
                       npz_name, run_reference_loop, save_tracks, segment_time_ok)
 from .utm import CameraModel, REF_UTM_FILTER, cam_to_utm, project_segment, project_tracks, utm_name  # noqa: F401
+from .sequence import track_image_sequence  # noqa: F401
 from ._lib import IcelkError  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,56 @@
+"""GPU: track_image_sequence (sequence.py) -- a folder of JPEGs through host decode, crop-on-upload, device-built mask
+and the device-resident loop -- against the reference-shaped loop run on the oracle over the same decoded pixels."""
+import datetime as dt
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_api import OracleCv
+
+pytestmark = pytest.mark.gpu
+
+
+def test_folder_of_jpegs_equals_reference_loop_on_oracle(orc, synth, tmp_path):
+    from PIL import Image
+    from iceberg_tracking_code_amd import run_reference_loop, track_image_sequence
+    w, h, n, T, dts = 720, 540, 9, 2, 60
+    grays, _ = synth.sequence(w, h, n, seed=31, max_step_px=2.0)
+    src, dst = tmp_path / "photos", tmp_path / "tracks"
+    src.mkdir()
+    dst.mkdir()
+    t0 = dt.datetime(2019, 7, 24, 10, 0, 0)
+    names = []
+    for k, g in enumerate(grays):
+        # frame 5 comes 30 s late: the segment 4..6 must be dropped by the time-gap rule (s1:364-390)
+        t = t0 + dt.timedelta(seconds=k * dts + (30 if k == 5 else 0))
+        rgb = np.stack([g, np.roll(g, 1, 1), np.roll(g, 1, 0)], 2)
+        p = src / (t.strftime("%Y%m%d-%H%M%S") + ".jpg")
+        Image.fromarray(rgb).save(p, quality=95)
+        names.append(str(p))
+    crop = (24, 60, 16, 8)
+    poly = [(40, 80), (700, 70), (690, 520), (300, 470), (50, 530)]
+    fp = dict(maxCorners=400, qualityLevel=0.007, minDistance=10, blockSize=10)
+    lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
+    got = track_image_sequence(names, str(dst), T, dts, crop=crop, mask_polygon=(poly, crop[0], crop[1]),
+                               feature_params=fp, lk_params=lk, decode_threads=3)
+    # the same on the CPU: PIL decode, numpy crop, oracle gray / mask / loop
+    decoded = [np.array(Image.open(p)) for p in names]
+    cropped = [np.ascontiguousarray(d[crop[1]:h - crop[3], crop[0]:w - crop[2]]) for d in decoded]
+    gray = [orc.bgr2gray(c, 3) for c in cropped]
+    mask = orc.polygon_mask(poly, crop[0], crop[1], gray[0].shape[1], gray[0].shape[0])
+    ref = run_reference_loop(gray, T, fp, lk, mask=mask, cv=OracleCv(orc))
+    want = []
+    for first, tracks, quality in ref:
+        seg_names = [os.path.basename(p) for p in names[first:first + T + 1]]
+        times = [dt.datetime.strptime(s, "%Y%m%d-%H%M%S.jpg") for s in seg_names]
+        if all((b - a).seconds in range(dts - 2, dts + 3) for a, b in zip(times[:-1], times[1:])):
+            want.append(("{}_{}sec_at_{}sec_tracks.npz".format(seg_names[0].split(".")[0], T * dts, dts),
+                         np.float32(tracks), np.float32(quality)))
+    assert len(ref) == 4 and len(want) == 3 and len(got) == 3
+    assert sorted(os.listdir(dst)) == sorted(nm for nm, _, _ in want)
+    for (path, tr, q), (nm, wt, wq) in zip(got, want):
+        assert os.path.basename(path) == nm and len(tr) > 100
+        z = np.load(path, allow_pickle=False)
+        assert np.array_equal(z["tracks"], wt) and np.array_equal(z["trackquality"], wq)
+        assert np.array_equal(tr, wt) and np.array_equal(q, wq)
