@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the projection epilogue (k_project_tracks): tracks/s on the GPU (kernel alone via HIP events, and
 through the C ABI with its PCIe transfers) beside the CPU oracle on the host cores (1 thread, scalar C).
-Usage: python tools/utm_bench.py [n_tracks] [n_vertices]"""
+Usage: python tests/utm_bench.py [n_tracks] [n_vertices]"""
 import json
 import os
 import sys
@@ -11,7 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import oracle  # noqa: E402
 import utm_golden as G  # noqa: E402
 from iceberg_tracking_code_amd import Context, project_tracks  # noqa: E402
