@@ -14,6 +14,7 @@ from .tracker import (LucasKanade, REF_FB_THRESHOLD, REF_FEATURE_PARAMS, REF_LK_
                       npz_name, run_reference_loop, save_tracks, segment_time_ok)
 from .utm import CameraModel, REF_UTM_FILTER, cam_to_utm, project_segment, project_tracks, utm_name  # noqa: F401
 from .sequence import track_image_sequence  # noqa: F401
+from .gridding import bin_velocities, create_grid_across_fjord, points_in_polygon  # noqa: F401
 from ._lib import IcelkError  # noqa: F401
 
 __version__ = "0.1.0"

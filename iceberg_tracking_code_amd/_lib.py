@@ -62,6 +62,9 @@ SIGNATURES = {
     "icelk_seg_live": (C.c_int, [handle_p, i32p, i64p]),
     "icelk_project_tracks": (C.c_int, [handle_p, f32p, C.c_int, C.c_int, vp, vp, f64p, f64p, f64p, f64p, f64p, u8p]),
     "icelk_seg_project": (C.c_int, [handle_p, vp, vp, C.c_int, C.c_int, f64p, f64p, f64p, f64p, f64p, u8p, i32p, i32p]),
+    "icelk_points_in_polygon": (C.c_int, [handle_p, f64p, C.c_int, f64p, C.c_int, u8p]),
+    "icelk_grid_bin": (C.c_int, [handle_p, f64p, f64p, f64p, f64p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                                 C.c_int, u8p, i32p, f64p, f64p, f64p]),
     "icelk_seg_read": (C.c_int, [handle_p, f32p, f32p, C.c_int, C.c_int, i32p, i32p]),
     "icelk_prof_enable": (C.c_int, [handle_p, C.c_int]),
     "icelk_prof_reset": (C.c_int, [handle_p]),

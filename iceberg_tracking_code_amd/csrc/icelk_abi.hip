@@ -672,6 +672,23 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
     return ICELK_OK;
 }
 
+struct DevBufs {   // frees whatever was allocated when it goes out of scope
+    std::vector<void*> p;
+    ~DevBufs()
+    {
+        for (void* q : p)
+            if (q) hipFree(q);
+    }
+    template <typename T>
+    T* get(size_t count)
+    {
+        void* q = nullptr;
+        if (hipMalloc(&q, sizeof(T) * (count ? count : 1)) != hipSuccess) return nullptr;
+        p.push_back(q);
+        return reinterpret_cast<T*>(q);
+    }
+};
+
 }  // namespace icelk
 
 using namespace icelk;
@@ -1411,6 +1428,103 @@ int icelk_seg_project(icelk_t* h, const icelk_camera_t* cam, const icelk_utm_fil
     rc = check_launch(c, "seg_gather");
     if (rc) return rc;
     return project_core(c, c->d_out_tracks, n, nv, cam, filt, max_vectors, x, y, u, v, speed, keep);
+}
+
+// ---- gridding of projected velocities (s3_utm_to_gridded_utm.py:391-421) ------------------------
+
+int icelk_points_in_polygon(icelk_t* h, const double* poly_xy, int n_poly, const double* pts_xy, int n_pts,
+                            uint8_t* inside)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n_poly < 0 || n_pts < 0 || (n_poly > 0 && !poly_xy) || (n_pts > 0 && (!pts_xy || !inside)))
+        FAIL(c, ICELK_EARG, "bad polygon / point arrays");
+    if (n_pts == 0) return ICELK_OK;
+    DevBufs B;
+    double* d_poly = B.get<double>(2 * (size_t)n_poly);
+    double* d_pts = B.get<double>(2 * (size_t)n_pts);
+    uint8_t* d_out = B.get<uint8_t>((size_t)n_pts);
+    if (!d_poly || !d_pts || !d_out) FAIL(c, ICELK_ENOMEM, "hipMalloc failed");
+    if (n_poly > 0)
+        HIPCHK(c, hipMemcpyAsync(d_poly, poly_xy, sizeof(double) * 2 * n_poly, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_pts, pts_xy, sizeof(double) * 2 * n_pts, hipMemcpyHostToDevice, c->stream));
+    launch_points_in_polygon(c->stream, d_poly, n_poly, d_pts, n_pts, d_out);
+    int rc = check_launch(c, "points_in_polygon");
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(inside, d_out, n_pts, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICELK_OK;
+}
+
+int icelk_grid_bin(icelk_t* h, const double* x, const double* y, const double* u, const double* v, int n, double left,
+                   double top, double spacing, int cols, int rows, const uint8_t* cell_on, int* count, double* mean_u,
+                   double* mean_v, double* speed)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n < 0 || cols <= 0 || rows <= 0 || !(spacing > 0) || !cell_on || !count || !mean_u || !mean_v || !speed ||
+        (n > 0 && (!x || !y || !u || !v)))
+        FAIL(c, ICELK_EARG, "bad gridding arguments");
+    if ((long long)cols * rows > (1 << 24) || n > (1 << 27)) FAIL(c, ICELK_ECAP, "grid or point set too large");
+    const int ncells = cols * rows;
+    // a point lies in one cell, or -- exactly on an edge / corner -- in up to four; 2 n + 1024 keys cover any set
+    // whose points are not all on edges, and the count is checked
+    const int key_cap = (int)std::min<long long>(2LL * n + 1024, 0x7fffffffLL);
+    DevBufs B;
+    double* dx = B.get<double>((size_t)n);
+    double* dy = B.get<double>((size_t)n);
+    double* du = B.get<double>((size_t)n);
+    double* dv = B.get<double>((size_t)n);
+    uint8_t* d_on = B.get<uint8_t>((size_t)ncells);
+    unsigned long long* keys = B.get<unsigned long long>((size_t)key_cap);
+    unsigned long long* keys_sorted = B.get<unsigned long long>((size_t)key_cap);
+    int* d_key_count = B.get<int>(1);
+    int* d_count = B.get<int>((size_t)ncells);
+    double* d_mu = B.get<double>((size_t)ncells);
+    double* d_mv = B.get<double>((size_t)ncells);
+    double* d_sp = B.get<double>((size_t)ncells);
+    if (!dx || !dy || !du || !dv || !d_on || !keys || !keys_sorted || !d_key_count || !d_count || !d_mu || !d_mv || !d_sp)
+        FAIL(c, ICELK_ENOMEM, "hipMalloc failed");
+    const hipStream_t s = c->stream;
+    const size_t nb = sizeof(double) * (size_t)n;
+    if (n > 0) {
+        HIPCHK(c, hipMemcpyAsync(dx, x, nb, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(dy, y, nb, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(du, u, nb, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(dv, v, nb, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(c, hipMemcpyAsync(d_on, cell_on, ncells, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(d_key_count, 0, sizeof(int), s));
+    launch_grid_assign(s, dx, dy, n, left, top, spacing, cols, rows, d_on, keys, d_key_count, key_cap);
+    int rc = check_launch(c, "grid_assign");
+    if (rc) return rc;
+    int total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, d_key_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (total > key_cap) FAIL(c, ICELK_ECAP, "more than two cells per point on average (all points on cell edges?)");
+    const unsigned long long* sorted = keys;
+    if (total > 1) {
+        int cell_bits = 1;
+        while ((1 << cell_bits) < ncells) cell_bits++;
+        const size_t tmp_bytes = sort_keys_asc(s, nullptr, 0, keys, keys_sorted, total, 32 + cell_bits);
+        void* tmp = B.get<uint8_t>(tmp_bytes);
+        if (!tmp) FAIL(c, ICELK_ENOMEM, "hipMalloc failed");
+        sort_keys_asc(s, tmp, tmp_bytes, keys, keys_sorted, total, 32 + cell_bits);
+        rc = check_launch(c, "grid sort");
+        if (rc) return rc;
+        sorted = keys_sorted;
+    }
+    launch_grid_reduce(s, sorted, d_key_count, du, dv, ncells, d_count, d_mu, d_mv, d_sp);
+    rc = check_launch(c, "grid_reduce");
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(count, d_count, sizeof(int) * ncells, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(mean_u, d_mu, sizeof(double) * ncells, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(mean_v, d_mv, sizeof(double) * ncells, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(speed, d_sp, sizeof(double) * ncells, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return ICELK_OK;
 }
 
 int icelk_seg_live(icelk_t* h, int* out_live, int64_t* out_tracked_total)

@@ -166,6 +166,13 @@ typedef icelk_camera_t UtmCamera;
 typedef icelk_utm_filter_t UtmFilter;
 void launch_project_tracks(hipStream_t s, const float* tracks, int n, int nv, const UtmCamera& cam, const UtmFilter& f,
                            double* x, double* y, double* u, double* v, double* speed, uint8_t* keep);
+void launch_points_in_polygon(hipStream_t s, const double* poly, int n, const double* pts, int m, uint8_t* out);
+void launch_grid_assign(hipStream_t s, const double* x, const double* y, int n, double left, double top, double spacing,
+                        int cols, int rows, const uint8_t* cell_on, unsigned long long* keys, int* key_count, int key_cap);
+void launch_grid_reduce(hipStream_t s, const unsigned long long* keys, const int* key_count, const double* u,
+                        const double* v, int ncells, int* count, double* mean_u, double* mean_v, double* speed);
+size_t sort_keys_asc(hipStream_t s, void* tmp, size_t tmp_bytes, const unsigned long long* in, unsigned long long* out,
+                     int n, int end_bit);
 void launch_polygon_mask(hipStream_t s, const double* poly, int n, double crop_left, double crop_top, int w, int h,
                          uint8_t* mask, int pitch);
 void launch_seg_order(hipStream_t s, const float* xy, int n, int w, int h, int* order);

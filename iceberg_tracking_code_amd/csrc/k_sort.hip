@@ -29,4 +29,14 @@ void sort_keys_desc(hipStream_t s, DetectScratch& D, const unsigned long long* i
     (void)rocprim::radix_sort_keys_desc(D.sort_tmp, bytes, in, out, (size_t)n, 0, 64, s);
 }
 
+// ascending sort of (cell << 32 | point index) keys for the gridding step (k_grid.hip); temporary storage is the
+// caller's (queried with tmp == nullptr)
+size_t sort_keys_asc(hipStream_t s, void* tmp, size_t tmp_bytes, const unsigned long long* in, unsigned long long* out,
+                     int n, int end_bit)
+{
+    size_t bytes = tmp_bytes;
+    (void)rocprim::radix_sort_keys(tmp, bytes, in, out, (size_t)(n > 0 ? n : 1), 0, (unsigned)end_bit, s);
+    return bytes;
+}
+
 }  // namespace icelk

@@ -192,6 +192,19 @@ int icelk_seg_project(icelk_t* h, const icelk_camera_t* cam, const icelk_utm_fil
                       double* x, double* y, double* u, double* v, double* speed, uint8_t* keep, int* out_n,
                       int* out_vectors);
 
+/* ---- gridding of the projected velocities (s3_utm_to_gridded_utm.py:391-421) --------------------------------
+ * matplotlib.path.Path(poly).contains_points(points) with radius 0 (the rule of icelk_set_mask_polygon) for arbitrary
+ * float64 points: used for "does the fjord outline contain the cell centre" (imports/tracking_misc.py:49). */
+int icelk_points_in_polygon(icelk_t* h, const double* poly_xy, int n_poly, const double* pts_xy, int n_pts,
+                            uint8_t* inside);
+/* Square cells of `spacing` from (left, top), cols x rows, cell (i, j) = column i, row j downwards, stored at
+ * i * rows + j as the reference walks them (tracking_misc.py:41-43); cell_on[] marks the cells the grid keeps.  For
+ * every kept cell: count of the n velocities (x, y, u, v; float64) whose position lies in it by contains_points'
+ * rule, and for count > 0 mean_u = np.sum(u_sel) / count (numpy's pairwise order), mean_v, speed = hypot. */
+int icelk_grid_bin(icelk_t* h, const double* x, const double* y, const double* u, const double* v, int n, double left,
+                   double top, double spacing, int cols, int rows, const uint8_t* cell_on, int* count, double* mean_u,
+                   double* mean_v, double* speed);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Per-kernel HIP-event timing on the handle's stream (bench.py's roofline leg). */
 int icelk_prof_enable(icelk_t* h, int on);

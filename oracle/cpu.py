@@ -39,7 +39,7 @@ class UtmFilter(C.Structure):
 
 def build(force=False):
     """Compile the C restatement with the committed Makefile (gcc only)."""
-    srcs = [os.path.join(_HERE, f) for f in ("icelk_oracle.c", "utm_oracle.c", "mask_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("icelk_oracle.c", "utm_oracle.c", "mask_oracle.c", "grid_oracle.c")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
@@ -68,6 +68,9 @@ def lib():
                                         C.c_double, C.c_int, _f32p, C.c_int, _i32p]
         L.orc_project_tracks.argtypes = [_f32p, C.c_int, C.c_int, C.POINTER(UtmCamera), C.POINTER(UtmFilter), _f64p,
                                          _f64p, _f64p, _f64p, _f64p, _u8p]
+        L.orc_points_in_polygon.argtypes = [_f64p, C.c_int, _f64p, C.c_int, _u8p]
+        L.orc_grid_bin.argtypes = [_f64p, _f64p, _f64p, _f64p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                                   C.c_int, _u8p, _i32p, _f64p, _f64p, _f64p]
         L.orc_polygon_mask.argtypes = [_f64p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _u8p, C.c_int]
         _lib = L
     return _lib
@@ -250,3 +253,26 @@ def polygon_mask(poly, crop_left, crop_top, w, h):
     m = np.zeros((h, w), np.uint8)
     _chk(lib().orc_polygon_mask(_p(p, _f64p), len(p), float(crop_left), float(crop_top), w, h, _p(m, _u8p), w))
     return m
+
+
+def points_in_polygon(poly, pts):
+    """grid_oracle.c: matplotlib's Path(poly).contains_points(pts) (radius 0) -> bool array."""
+    p = np.ascontiguousarray(poly, dtype=np.float64).reshape(-1, 2)
+    q = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros(len(q), np.uint8)
+    _chk(lib().orc_points_in_polygon(_p(p, _f64p), len(p), _p(q, _f64p), len(q), _p(out, _u8p)))
+    return out.astype(bool)
+
+
+def grid_bin(x, y, u, v, left, top, spacing, cols, rows, cell_on):
+    """grid_oracle.c: per cell (index i * rows + j) count, mean_u, mean_v, speed of the velocities inside it."""
+    a = [np.ascontiguousarray(t, dtype=np.float64).ravel() for t in (x, y, u, v)]
+    on = np.ascontiguousarray(cell_on, dtype=np.uint8).ravel()
+    nc = cols * rows
+    assert on.size == nc
+    cnt = np.zeros(nc, np.int32)
+    mu, mv, sp = (np.zeros(nc, np.float64) for _ in range(3))
+    _chk(lib().orc_grid_bin(_p(a[0], _f64p), _p(a[1], _f64p), _p(a[2], _f64p), _p(a[3], _f64p), len(a[0]), float(left),
+                            float(top), float(spacing), cols, rows, _p(on, _u8p), _p(cnt, _i32p), _p(mu, _f64p),
+                            _p(mv, _f64p), _p(sp, _f64p)))
+    return dict(count=cnt, mean_u=mu, mean_v=mv, speed=sp)
