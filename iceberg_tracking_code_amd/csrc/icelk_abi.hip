@@ -14,7 +14,7 @@ namespace icelk {
 constexpr int kMaxVert = 17;  // vertices per track kept on the device (track_len <= 16; reference uses 2)
 
 static const char* kKernelNames[K_COUNT_] = {
-    "bgr2gray", "pyrdown", "lk", "lk_fb", "corner_candidates", "unused5", "unused6", "min_distance", "sort_emit",
+    "bgr2gray", "pyrdown", "lk", "lk_fb", "corner_candidates", "min_distance", "sort_emit",
     "project_tracks", "synth",
 };
 

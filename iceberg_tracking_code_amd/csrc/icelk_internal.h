@@ -41,8 +41,6 @@ enum KernelId {
     K_LK,
     K_LK_FB,
     K_EIG,
-    K_NMS,
-    K_CELLS,
     K_SUPPRESS,
     K_EMIT,
     K_PROJECT,
