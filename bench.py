@@ -230,7 +230,7 @@ def main():
     # the same kernels once more, each ALONE on the device (outside the timed region): inside the pipeline their
     # HIP-event durations include waiting for wave slots beside the tracker launch
     alone = {}
-    if rank == 0 and not args.no_kernel_timing:
+    if rank == 0 and not args.no_kernel_timing and not host:   # the resident ring provides the frames
         bs = DETECT["blockSize"]
         for _ in range(2):   # first pass warms up
             ctx.sync()
