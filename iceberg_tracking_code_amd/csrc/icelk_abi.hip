@@ -436,7 +436,7 @@ static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
     T.max_key = e.max_key;
     {
         ProfScope p(c, K_EIG, es);
-        launch_candidates(es, T, s.lv[0], block_size, mask, c->mask_pitch, 1.0, false, nullptr);
+        launch_candidates(es, T, s.lv[0], block_size, mask, c->mask_pitch, 1.0, false, nullptr, true);
     }
     rc = check_launch(c, "corner candidates (prepared)");
     if (rc) return rc;

@@ -25,6 +25,8 @@
 // gfx950), and the masked maximum is published with a read-guarded atomicMax.
 // The whole detection is enqueued without host round trips; the host synchronises once, to learn the
 // number of accepted corners.
+#include <cstdlib>
+
 #include "icelk_internal.h"
 
 namespace icelk {
@@ -295,6 +297,221 @@ __global__ __launch_bounds__(256) void k_eig_nms(const uint8_t* __restrict__ img
     __syncthreads();
 
     // 4. 3x3 non-max test; survivors go straight to this workgroup's region of the candidate buffer
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    unsigned long long* region = raw + (size_t)bid * (C::TW * C::TH);
+    for (int i = tid; i < C::TW * C::TH; i += 256) {
+        const int oy = i / C::TW, ox = i - oy * C::TW;
+        const int x = x0 + ox, y = y0 + oy;
+        if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) continue;
+        const float* e = E + (oy + 1) * C::EW + (ox + 1);
+        const float v = e[0];
+        if (!(v > 0.f)) continue;
+        float m = e[-C::EW - 1];
+        m = fmaxf(m, e[-C::EW]); m = fmaxf(m, e[-C::EW + 1]);
+        m = fmaxf(m, e[-1]); m = fmaxf(m, e[1]);
+        m = fmaxf(m, e[C::EW - 1]); m = fmaxf(m, e[C::EW]); m = fmaxf(m, e[C::EW + 1]);
+        if (v < m) continue;
+        if (mask && !mask[(size_t)y * mask_pitch + x]) continue;
+        region[atomicAdd(&s_list_n, 1)] = ((unsigned long long)ordered_key(v) << 32) | pack_xy(x, y);
+    }
+    __syncthreads();
+    if (tid == 0) blk_count[bid] = s_list_n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused K6+K7, second form: the same arithmetic with 33 KB of LDS instead of 70 KB (4 workgroups per CU instead
+// of 2 -- the first form is occupancy-bound: 337 us alone against an issue floor of 110 us).  Only the two
+// derivative planes are kept (the covariance products are formed where they are summed, each with the same single
+// f32 rounding), and the double row sums of ONE plane at a time: row pass -> barrier -> column pass into registers
+// -> barrier, three times.  Sums run in the same order as in the first form, so results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <int BS>
+struct EigCfg2 {
+    static constexpr int TW = 64, TH = 16;
+    static constexpr int EW = TW + 2, EH = TH + 2;
+    static constexpr int CW = EW + BS - 1, CH = EH + BS - 1;
+    static constexpr int CWP = (CW + 3) & ~3;
+    static constexpr int UW = CW + 2, UH = CH + 2;
+    static constexpr int UPD = (UW + 2) / 4 + 1;
+    static constexpr int AN = BS / 2;
+    static constexpr int RX = 6, RY = 6;
+    static constexpr int NGX = EW / RX, NGY = EH / RY;
+    static_assert(EW % RX == 0 && EH % RY == 0, "blocking must divide the tile");
+    static_assert(EW * NGY <= 256, "one column task per thread");
+    static constexpr int U_BYTES = (UPD * UH * 4 + 15) & ~15;
+    static constexpr int D_BYTES = 2 * CH * CWP * 4;          // dx, dy
+    static constexpr int A_BYTES = U_BYTES + D_BYTES;         // later reused for the eigenvalue tile
+    static constexpr int HS_BYTES = CH * EW * 8;              // row sums of one plane
+    static constexpr int LDS_BYTES = A_BYTES + HS_BYTES;
+    static_assert(EW * EH * 4 <= A_BYTES, "eigenvalue tile must fit the dead derivative region");
+};
+
+__device__ __forceinline__ void sobel_d(float a0, float b0, float c0, float a1, float c1, float a2, float b2, float c2,
+                                        float k0, float k1, float& dx, float& dy)
+{
+    dx = __fadd_rn(__fmul_rn(__fadd_rn(__fsub_rn(c0, a0), __fsub_rn(c2, a2)), k1), __fmul_rn(__fsub_rn(c1, a1), k0));
+    const float t0 = __fadd_rn(__fadd_rn(__fmul_rn(k1, a0), __fmul_rn(k0, b0)), __fmul_rn(k1, c0));
+    const float t2 = __fadd_rn(__fadd_rn(__fmul_rn(k1, a2), __fmul_rn(k0, b2)), __fmul_rn(k1, c2));
+    dy = __fsub_rn(t2, t0);
+}
+
+__device__ __forceinline__ void sobel_d2(f2 a0, f2 b0, f2 c0, f2 a1, f2 c1, f2 a2, f2 b2, f2 c2, float k0, float k1,
+                                         f2& dx, f2& dy)
+{
+    dx = ((c0 - a0) + (c2 - a2)) * k1 + (c1 - a1) * k0;
+    const f2 t0 = (a0 * k1 + b0 * k0) + c0 * k1;
+    const f2 t2 = (a2 * k1 + b2 * k0) + c2 * k1;
+    dy = t2 - t0;
+}
+
+template <int BS>
+__global__ __launch_bounds__(256) void k_eig_nms2(const uint8_t* __restrict__ img, int w, int h, int pitch, float k0,
+                                                  float k1, const uint8_t* __restrict__ mask, int mask_pitch,
+                                                  unsigned* __restrict__ max_key,
+                                                  unsigned long long* __restrict__ raw, int* __restrict__ blk_count,
+                                                  float* __restrict__ eig_out)
+{
+    using C = EigCfg2<BS>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* U = reinterpret_cast<uint32_t*>(smem);
+    float* D = reinterpret_cast<float*>(smem + C::U_BYTES);        // [2][CH][CWP]: dx, dy
+    double* hs = reinterpret_cast<double*>(smem + C::A_BYTES);     // [CH][EW]
+    float* E = reinterpret_cast<float*>(smem);                     // after the last row pass
+    __shared__ int s_list_n;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * C::TW, y0 = blockIdx.y * C::TH;
+    const int ux0 = x0 - 2 - C::AN, uy0 = y0 - 2 - C::AN;
+    const bool interior = ux0 >= 0 && uy0 >= 0 && ux0 + C::UW <= w && uy0 + C::UH <= h;
+    constexpr int DP = C::CH * C::CWP;   // plane stride
+
+    if (interior) {
+        const uint8_t* base = img + (size_t)uy0 * pitch + (ux0 & ~3);
+        for (int i = tid; i < C::UPD * C::UH; i += 256) {
+            const int r = i / C::UPD, c = i - r * C::UPD;
+            U[i] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * c);
+        }
+        __syncthreads();
+        const int cs = ux0 & 3;
+        constexpr int NQF = C::CW / 4, REM = C::CW - 4 * NQF;
+        for (int t = tid; t < C::CH * NQF; t += 256) {
+            const int cy = t / NQF, q = t - cy * NQF;
+            float F[3][6];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const uint32_t* p = U + (cy + r) * C::UPD + ((cs + 4 * q) >> 2);
+                const int sh = (cs + 4 * q) & 3;
+                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+                const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, sh), e1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                F[r][0] = (float)(e0 & 255); F[r][1] = (float)((e0 >> 8) & 255); F[r][2] = (float)((e0 >> 16) & 255);
+                F[r][3] = (float)(e0 >> 24); F[r][4] = (float)(e1 & 255); F[r][5] = (float)((e1 >> 8) & 255);
+            }
+            f2 dx[2], dy[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int j = 2 * i;
+                sobel_d2(f2{F[0][j], F[0][j + 1]}, f2{F[0][j + 1], F[0][j + 2]}, f2{F[0][j + 2], F[0][j + 3]},
+                         f2{F[1][j], F[1][j + 1]}, f2{F[1][j + 2], F[1][j + 3]},
+                         f2{F[2][j], F[2][j + 1]}, f2{F[2][j + 1], F[2][j + 2]}, f2{F[2][j + 2], F[2][j + 3]},
+                         k0, k1, dx[i], dy[i]);
+            }
+            float* c = D + cy * C::CWP + 4 * q;
+            *reinterpret_cast<float4*>(c) = make_float4(dx[0].x, dx[0].y, dx[1].x, dx[1].y);
+            *reinterpret_cast<float4*>(c + DP) = make_float4(dy[0].x, dy[0].y, dy[1].x, dy[1].y);
+        }
+        if (REM > 0) {
+            const uint8_t* Ub = reinterpret_cast<const uint8_t*>(U);
+            for (int i = tid; i < C::CH * REM; i += 256) {
+                const int cy = i / REM, cx = 4 * NQF + (i - cy * REM);
+                const uint8_t* r0 = Ub + cy * C::UPD * 4 + cs + cx;
+                const uint8_t* r1 = r0 + C::UPD * 4;
+                const uint8_t* r2 = r1 + C::UPD * 4;
+                float dx, dy;
+                sobel_d((float)r0[0], (float)r0[1], (float)r0[2], (float)r1[0], (float)r1[2], (float)r2[0], (float)r2[1],
+                        (float)r2[2], k0, k1, dx, dy);
+                D[cy * C::CWP + cx] = dx;
+                D[DP + cy * C::CWP + cx] = dy;
+            }
+        }
+    } else {
+        for (int i = tid; i < C::CH * C::CW; i += 256) {
+            const int cy = i / C::CW, cx = i - cy * C::CW;
+            const int rx = reflect101(ux0 + 1 + cx, w), ry = reflect101(uy0 + 1 + cy, h);
+            const int xm = reflect101(rx - 1, w), xp = reflect101(rx + 1, w);
+            const int ym = reflect101(ry - 1, h), yp = reflect101(ry + 1, h);
+            const uint8_t* r0 = img + (size_t)ym * pitch;
+            const uint8_t* r1 = img + (size_t)ry * pitch;
+            const uint8_t* r2 = img + (size_t)yp * pitch;
+            float dx, dy;
+            sobel_d((float)r0[xm], (float)r0[rx], (float)r0[xp], (float)r1[xm], (float)r1[xp], (float)r2[xm],
+                    (float)r2[rx], (float)r2[xp], k0, k1, dx, dy);
+            D[cy * C::CWP + cx] = dx;
+            D[DP + cy * C::CWP + cx] = dy;
+        }
+    }
+    __syncthreads();
+
+    // three planes in turn: xx = dx*dx, xy = dx*dy, yy = dy*dy (one f32 rounding each, as the stored planes of the
+    // first form had); row sums left to right into hs, column sums top to bottom into registers
+    const bool col_task = tid < C::EW * C::NGY;
+    const int cg = tid / C::EW, cex = tid - cg * C::EW;   // column task: group of RY rows, column
+    double S[3][C::RY];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        const float* A = D + (p == 2 ? DP : 0);
+        const float* Bp = D + (p == 0 ? 0 : DP);
+        for (int t = tid; t < C::CH * C::NGX; t += 256) {
+            const int cy = t / C::NGX, g = t - cy * C::NGX;
+            const float* a = A + cy * C::CWP + g * C::RX;
+            const float* b = Bp + cy * C::CWP + g * C::RX;
+            double v[C::RX + BS - 1];
+#pragma unroll
+            for (int i = 0; i < C::RX + BS - 1; i++) v[i] = (double)__fmul_rn(a[i], b[i]);
+            double* o = hs + cy * C::EW + g * C::RX;
+#pragma unroll
+            for (int i = 0; i < C::RX; i++) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < BS; k++) s += v[i + k];
+                o[i] = s;
+            }
+        }
+        __syncthreads();
+        if (col_task) {
+            double v[C::RY + BS - 1];
+#pragma unroll
+            for (int i = 0; i < C::RY + BS - 1; i++) v[i] = hs[(cg * C::RY + i) * C::EW + cex];
+#pragma unroll
+            for (int i = 0; i < C::RY; i++) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < BS; k++) s += v[i + k];
+                S[p][i] = s;
+            }
+        }
+        __syncthreads();   // hs is rewritten by the next plane; after the last one D is dead as well
+    }
+
+    unsigned best = 0;
+    if (col_task) {
+#pragma unroll
+        for (int i = 0; i < C::RY; i++) {
+            const float e = min_eig_of(S[0][i], S[1][i], S[2][i]);
+            const int ey = cg * C::RY + i;
+            E[ey * C::EW + cex] = e;
+            const int x = x0 - 1 + cex, y = y0 - 1 + ey;
+            if (cex >= 1 && cex <= C::TW && ey >= 1 && ey <= C::TH && x < w && y < h) {
+                if (eig_out) eig_out[(size_t)y * w + x] = e;
+                if (!mask || mask[(size_t)y * mask_pitch + x]) {
+                    const unsigned k = ordered_key(e);
+                    best = k > best ? k : best;
+                }
+            }
+        }
+    }
+    publish_max(max_key, best, tid);
+    if (tid == 0) s_list_n = 0;
+    __syncthreads();
+
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
     unsigned long long* region = raw + (size_t)bid * (C::TW * C::TH);
     for (int i = tid; i < C::TW * C::TH; i += 256) {
@@ -764,18 +981,28 @@ void sobel_scale(int block_size, float* k0, float* k1)
 
 template <int BS>
 void launch_fused(hipStream_t s, const Level& img, float k0, float k1, const uint8_t* mask, int mask_pitch,
-                  unsigned* max_key, unsigned long long* raw, int* blk_count, float* eig_out, CandSrc* src)
+                  unsigned* max_key, unsigned long long* raw, int* blk_count, float* eig_out, CandSrc* src,
+                  bool background)
 {
     using C = EigCfg<BS>;
+    using C2 = EigCfg2<BS>;
+    static const char* form_env = getenv("ICELK_EIG_FORM");   // "1" / "2": force one form (A/B measurements)
+    const bool first_form = form_env ? form_env[0] == '1' : background;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eig_nms<BS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             C::LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eig_nms2<BS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C2::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid((img.w + C::TW - 1) / C::TW, (img.h + C::TH - 1) / C::TH);
-    hipLaunchKernelGGL((k_eig_nms<BS>), grid, dim3(256), C::LDS_BYTES, s, img.ptr, img.w, img.h, img.pitch, k0, k1,
-                       mask, mask_pitch, max_key, raw, blk_count, eig_out);
+    if (first_form)
+        hipLaunchKernelGGL((k_eig_nms<BS>), grid, dim3(256), C::LDS_BYTES, s, img.ptr, img.w, img.h, img.pitch, k0, k1,
+                           mask, mask_pitch, max_key, raw, blk_count, eig_out);
+    else
+        hipLaunchKernelGGL((k_eig_nms2<BS>), grid, dim3(256), C2::LDS_BYTES, s, img.ptr, img.w, img.h, img.pitch, k0, k1,
+                           mask, mask_pitch, max_key, raw, blk_count, eig_out);
     src->keys = raw;
     src->blk_count = blk_count;
     src->nblk = (int)(grid.x * grid.y);
@@ -843,7 +1070,7 @@ void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, bool full)
 
 // Candidate collection (K6+K7) into regions of D.raw (stream order, no host sync).
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
-                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null)
+                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null, bool background)
 {
     unsigned long long* raw = D.raw;
     CandSrc g_src{};
@@ -851,10 +1078,10 @@ void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int bl
         float k0, k1;
         sobel_scale(block_size, &k0, &k1);
         switch (block_size) {
-            case 3: launch_fused<3>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
-            case 5: launch_fused<5>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
-            case 7: launch_fused<7>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
-            default: launch_fused<10>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
+            case 3: launch_fused<3>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, background); break;
+            case 5: launch_fused<5>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, background); break;
+            case 7: launch_fused<7>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, background); break;
+            default: launch_fused<10>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, background); break;
         }
     } else {
         launch_min_eig(s, img, block_size, D.eig, mask, mask_pitch, D.max_key);
