@@ -89,3 +89,15 @@ def test_cv2_constants():
     assert cv.REF_LK_PARAMS["winSize"] == (35, 35) and cv.REF_LK_PARAMS["maxLevel"] == 4
     assert cv.REF_LK_PARAMS["criteria"] == (3, 25, 0.03)
     assert cv.REF_FEATURE_PARAMS == dict(maxCorners=50000000, qualityLevel=0.007, minDistance=10, blockSize=10)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/icelk.h is a C header: a C11 caller (tests/abi_smoke.c) compiles against it with gcc, warnings as
+    errors, and links against the shared library without any C++ or torch symbol in the way."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    obj = tmp_path / "abi_smoke.o"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), "-c",
+                           os.path.join(here, "abi_smoke.c"), "-o", str(obj)])
+    assert obj.stat().st_size > 0

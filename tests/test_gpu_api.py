@@ -186,3 +186,23 @@ def test_crop_during_upload_equals_cropping_first(orc, synth):
         c.upload_bgr(0, rgb, 3, crop=(400, 0, 301, 0))
     c.close()
     assert a.shape == (503 - 106, 701 - 51) and np.array_equal(a, b) and np.array_equal(a, orc.bgr2gray(cropped, 3))
+
+
+def test_plain_c_caller(tmp_path):
+    """tests/abi_smoke.c built with gcc against include/icelk.h + libicelk.so and run as a process of its own: the
+    boundary is usable without Python (detect 200 corners, track them forward-backward into a shifted frame)."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    libdir = os.path.join(root, "iceberg_tracking_code_amd")
+    exe = tmp_path / "abi_smoke"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-I", os.path.join(root, "include"),
+                           os.path.join(here, "abi_smoke.c"), "-o", str(exe), "-L", libdir, "-licelk",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    f = out.stdout.split()
+    assert f[0] == "corners" and int(f[1]) == 200 and int(f[3]) > 150
+    # the second frame samples the texture 300/256 px further right and 200/256 px further up: content moves the other way
+    assert abs(float(f[5]) + 300 / 256.0) < 0.05 and abs(float(f[6]) - 200 / 256.0) < 0.05
