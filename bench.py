@@ -261,8 +261,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        rccl = dist.new_group(backend="nccl")     # RCCL over xGMI
-        tracked_all = [int(v) for v in sharding.gather_counts([tracked], dist, device="cuda", group=rccl)]
+        gather_backend = "rccl"
+        try:
+            rccl = dist.new_group(backend="nccl")     # RCCL over xGMI
+            tracked_all = [int(v) for v in sharding.gather_counts([tracked], dist, device="cuda", group=rccl)]
+        except Exception as exc:                      # the line is still worth printing: same counts over gloo
+            sys.stderr.write("RCCL gather failed (%s); using gloo\n" % exc)
+            gather_backend = "gloo (RCCL failed)"
+            tracked_all = [int(v) for v in sharding.gather_counts([tracked], dist)]
 
     if rank == 0:
         top = top_level_of(w, h, cfg["win"], cfg["max_level"])
@@ -279,7 +285,8 @@ def main():
                        "criteria": list(cfg["criteria"]), "track_len": TRACK_LEN, "detector": DETECT,
                        "frames_resident": ring,
                        "source": "pinned host memory, hipMemcpyAsync double-buffered" if host else "HBM-resident",
-                       "sharding": "independent segments per rank, no data-path collective"},
+                       "sharding": "independent segments per rank, no data-path collective",
+                       "count_gather": gather_backend if dist is not None else None},
         }
         kern = {}
         lkp = prof.get("lk_fb")
