@@ -332,6 +332,13 @@ def main():
                 tj = json.load(open(traffic_file))
                 out["roofline"]["traffic"] = tj.get("lk_fb_bytes_per_launch")
                 out["roofline"]["traffic_source"] = tj.get("source")
+                if tj.get("lk_fb_valu_insts_per_launch") and tj.get("valu_issue_peak_per_s"):
+                    # the bound this kernel actually runs into: VALU issue (PMC SQ_INSTS_VALU per launch, same file)
+                    rate = tj["lk_fb_valu_insts_per_launch"] / (out["roofline"]["avg_launch_us"] * 1e-6)
+                    out["roofline"]["valu_issue"] = {"wave_instructions_per_launch": tj["lk_fb_valu_insts_per_launch"],
+                                                     "achieved_per_s": rate, "peak_per_s": tj["valu_issue_peak_per_s"],
+                                                     "frac": rate / tj["valu_issue_peak_per_s"],
+                                                     "peak_source": tj.get("valu_issue_peak_source")}
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
