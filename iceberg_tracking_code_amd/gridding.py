@@ -27,32 +27,24 @@ def points_in_polygon(ctx, poly, points):
     return out.astype(bool)
 
 
-def create_squares(origin, width, height):
-    """tracking_misc.py:14-21."""
-    x, y = origin[0], origin[1]
-    poly = [(x, y), (x + width, y), (x + width, y - width), (x, y - width)]
-    point = [x + 0.5 * width, y - 0.5 * height]
-    return [poly, point]
-
-
 def create_grid_across_fjord(ctx, fjord, spacing):
-    """tracking_misc.py:23-56: [polygons, centerpoints, indices, topleft_px_center, rows, cols] -- squares of `spacing`
-    from the top-left corner of the fjord outline, kept when the outline contains the cell centre (tested on the
-    GPU for all cells at once).  `fjord` has 'x' and 'y' arrays."""
+    """What trm.create_grid_across_fjord returns (tracking_misc.py:23-56): [polygons, centerpoints, indices,
+    topleft_px_center, rows, cols] -- squares of `spacing` laid from the top-left corner of the fjord outline, column
+    by column, kept when the outline contains the cell centre.  All cells are formed at once (the same float64
+    expressions per cell: corner = left + i * spacing, top - j * spacing; centre = corner +/- 0.5 * spacing) and the
+    containment test runs on the GPU for all centres together.  `fjord` has 'x' and 'y' arrays."""
     fx, fy = np.asarray(fjord["x"]), np.asarray(fjord["y"])
-    topleft = [min(fx), max(fy)]
-    topleft_px_center = [min(fx) + 0.5 * spacing, max(fy) - 0.5 * spacing]
-    cols = int(math.ceil((max(fx) - min(fx)) / spacing))
-    rows = int(math.ceil((max(fy) - min(fy)) / spacing))
-    cells = []
-    for i in range(cols):
-        for j in range(rows):
-            origin = [topleft[0] + i * spacing, topleft[1] - j * spacing]
-            poly, point = create_squares(origin, spacing, spacing)
-            cells.append((poly, point, [i, j]))
-    inside = points_in_polygon(ctx, np.vstack((fx, fy)).T, [c[1] for c in cells]) if cells else []
-    kept = [c for c, ok in zip(cells, inside) if ok]
-    return [[c[0] for c in kept], [c[1] for c in kept], [c[2] for c in kept], topleft_px_center, rows, cols]
+    left, right, bottom, top = min(fx), max(fx), min(fy), max(fy)
+    cols = int(math.ceil((right - left) / spacing))
+    rows = int(math.ceil((top - bottom) / spacing))
+    ii, jj = (a.ravel() for a in np.meshgrid(np.arange(cols), np.arange(rows), indexing="ij"))   # i-major, as s3 walks
+    ox, oy = left + ii * spacing, top - jj * spacing
+    centers = np.stack([ox + 0.5 * spacing, oy - 0.5 * spacing], 1)
+    keep = points_in_polygon(ctx, np.vstack((fx, fy)).T, centers) if len(centers) else np.zeros(0, bool)
+    polygons = [[(x, y), (x + spacing, y), (x + spacing, y - spacing), (x, y - spacing)]
+                for x, y in zip(ox[keep], oy[keep])]
+    return [polygons, [list(c) for c in centers[keep]], [[int(i), int(j)] for i, j in zip(ii[keep], jj[keep])],
+            [left + 0.5 * spacing, top - 0.5 * spacing], rows, cols]
 
 
 def bin_velocities(ctx, x, y, u, v, fjord, spacing, observation_threshold, grid=None):
