@@ -252,6 +252,9 @@ static int begin_frame(Ctx* c, int slot, int w, int h)
     if (w <= 0 || h <= 0) FAIL(c, ICELK_EARG, "empty image");
     if (w > c->max_w || h > c->max_h) FAIL(c, ICELK_ECAP, "frame larger than max_w x max_h of icelk_create");
     Slot& s = c->slots[slot];
+    // a detector launch on another stream may still read the frame this slot holds (compute-stream ingest paths
+    // write level 0 right after this call; the copy-stream path waits for the same event itself)
+    HIPCHK(c, hipStreamWaitEvent(c->stream, s.det_used, 0));
     s.w = w;
     s.h = h;
     layout_levels(s, w, h);
