@@ -27,6 +27,7 @@ SIGNATURES = {
     "icelk_destroy": (C.c_int, [handle_p]),
     "icelk_set_stream": (C.c_int, [handle_p, vp]),
     "icelk_sync": (C.c_int, [handle_p]),
+    "icelk_set_fb_distance": (C.c_int, [handle_p, C.c_int]),
     "icelk_upload_gray": (C.c_int, [handle_p, C.c_int, u8p, C.c_int, C.c_int, C.c_int]),
     "icelk_upload_bgr": (C.c_int, [handle_p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "icelk_set_gray_device": (C.c_int, [handle_p, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
@@ -43,6 +44,7 @@ SIGNATURES = {
     "icelk_track_fb": (C.c_int, [handle_p, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_double, C.c_double, C.c_float, f32p, f32p, u8p, u8p, f32p, f32p, f32p,
                                  u8p]),
+    "icelk_fb_filter": (C.c_int, [handle_p, f32p, f32p, C.c_int, C.c_float, f32p, u8p]),
     "icelk_set_mask": (C.c_int, [handle_p, u8p, C.c_int, C.c_int, C.c_int]),
     "icelk_min_eig_map": (C.c_int, [handle_p, C.c_int, C.c_int, f32p, C.c_int]),
     "icelk_good_features": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, f32p,

@@ -17,11 +17,12 @@ from .context import (Context, DEFAULT_CRITERIA, GRAY_CV3, GRAY_CV4, OPTFLOW_LK_
 COLOR_BGR2GRAY = 6
 COLOR_RGB2GRAY = 7
 
-_default = {"ctx": None, "gray_variant": GRAY_CV3, "device": 0}
+_default = {"ctx": None, "gray_variant": GRAY_CV4, "device": 0}
 
 
 def set_gray_variant(variant):
-    """3 = OpenCV 3.x 14-bit coefficients (default, README.md:8 of the reference), 4 = OpenCV 4.x 15-bit."""
+    """4 = OpenCV 4.x 15-bit coefficients (default: the reference's environment.yml:254 pins opencv 4.9.0),
+    3 = OpenCV 3.x 14-bit (the "3.1.0" its README.md:8 mentions)."""
     if variant not in (GRAY_CV3, GRAY_CV4):
         raise ValueError("variant must be 3 or 4")
     _default["gray_variant"] = variant

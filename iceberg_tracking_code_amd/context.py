@@ -17,6 +17,8 @@ OPTFLOW_USE_INITIAL_FLOW = 4
 OPTFLOW_LK_GET_MIN_EIGENVALS = 8
 GRAY_CV3 = 3
 GRAY_CV4 = 4
+FB_HYPOT = 0
+FB_SQRT = 1
 
 DEFAULT_CRITERIA = (TERM_CRITERIA_COUNT | TERM_CRITERIA_EPS, 30, 0.01)
 
@@ -80,12 +82,16 @@ class Context:
     def sync(self):
         self._ck(self._lib.icelk_sync(self._h))
 
+    def set_fb_distance(self, form):
+        """FB_HYPOT (np.hypot on float32, s1:330; default) or FB_SQRT ((dx**2+dy**2)**0.5, s0_1:99)."""
+        self._ck(self._lib.icelk_set_fb_distance(self._h, int(form)))
+
     # -- ingest -------------------------------------------------------------------------------
     def upload_gray(self, slot, img):
         a = _gray2d(img)
         self._ck(self._lib.icelk_upload_gray(self._h, slot, _u8(a), a.shape[1], a.shape[0], a.strides[0]))
 
-    def upload_bgr(self, slot, img, variant=GRAY_CV3, crop=None):
+    def upload_bgr(self, slot, img, variant=GRAY_CV4, crop=None):
         """3-channel frame -> gray in `slot` (s1:310-311).  `crop` = (left, top, right, bottom) pixels to drop, the
         box `Camera.crop_image` cuts (camtools.py:213-231): only the kept region crosses PCIe, straight out of the
         decoded frame (the reference's lossy JPEG re-save of the crop, s1:272, has no counterpart)."""
@@ -104,7 +110,7 @@ class Context:
     def set_gray_device(self, slot, dev_ptr, w, h, stride):
         self._ck(self._lib.icelk_set_gray_device(self._h, slot, C.c_void_p(dev_ptr), w, h, stride))
 
-    def cvt_bgr_device(self, slot, dev_ptr, w, h, stride, variant=GRAY_CV3):
+    def cvt_bgr_device(self, slot, dev_ptr, w, h, stride, variant=GRAY_CV4):
         self._ck(self._lib.icelk_cvt_bgr_device(self._h, slot, C.c_void_p(dev_ptr), w, h, stride, variant))
 
     def upload_gray_async(self, slot, pinned_ptr, w, h, stride):
@@ -172,6 +178,17 @@ class Context:
                                           _f32(out["err_fwd"]), _f32(out["err_bwd"]), _f32(out["dist"]),
                                           _u8(out["valid"])))
         return out
+
+    def fb_filter(self, p0, p0r, fb_threshold=1.0):
+        """(dist, valid) of s1:329-333 for given p0 / p0r, computed by the tracker's own device function."""
+        a = np.ascontiguousarray(p0, dtype=np.float32).reshape(-1, 2)
+        b = np.ascontiguousarray(p0r, dtype=np.float32).reshape(-1, 2)
+        if a.shape != b.shape:
+            raise ValueError("p0 and p0r differ in length")
+        n = a.shape[0]
+        dist, valid = np.zeros(n, np.float32), np.zeros(n, np.uint8)
+        self._ck(self._lib.icelk_fb_filter(self._h, _f32(a), _f32(b), n, float(fb_threshold), _f32(dist), _u8(valid)))
+        return dist, valid
 
     # -- detector -----------------------------------------------------------------------------
     def set_mask(self, mask):

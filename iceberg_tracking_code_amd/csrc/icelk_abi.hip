@@ -89,6 +89,7 @@ struct Ctx {
     hipEvent_t seg_ready = nullptr;   // the current set has been initialised (detection stream)
     bool seg_ready_pending = false;   // ... and the compute stream has not been told to wait for it yet
     bool use_order = true;                 // ICELK_NO_ORDER=1 launches in detector order (A/B measurements)
+    int fb_dist_form = ICELK_FB_HYPOT;     // icelk_set_fb_distance
     unsigned long long* d_tracked = nullptr;   // 64 sharded counters
     unsigned long long* h_seg = nullptr;   // pinned: {alive tracks, features tracked}
     float *d_out_tracks = nullptr, *d_out_quality = nullptr;
@@ -310,6 +311,7 @@ static int make_lk_params(Ctx* c, int w, int h, int win_w, int win_h, int max_le
     P->min_eig_thr = (float)min_eig_thr;
     P->fb_thr = fb_thr;
     P->margin = 6;
+    P->dist_form = c->fb_dist_form;
     return ICELK_OK;
 }
 
@@ -831,9 +833,22 @@ int icelk_sync(icelk_t* h)
 {
     if (!h) return ICELK_EARG;
     Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    // every stream of the handle: uploads / pyramids built ahead, candidate kernels of a prepared detection
+    // (icelk_seg_detect_prepare), the min-distance / sort / emit stage, tracker launches
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->eig_stream));
     HIPCHK(c, hipStreamSynchronize(c->det_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICELK_OK;
+}
+
+int icelk_set_fb_distance(icelk_t* h, int form)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    if (form != ICELK_FB_HYPOT && form != ICELK_FB_SQRT) FAIL(c, ICELK_EARG, "bad forward-backward distance form");
+    c->fb_dist_form = form;
     return ICELK_OK;
 }
 
@@ -1147,6 +1162,27 @@ int icelk_track_fb(icelk_t* h, int slot0, int slot1, const float* p0, int n, int
     if (err_fwd) HIPCHK(c, hipMemcpyAsync(err_fwd, c->d_err_f, fb, hipMemcpyDeviceToHost, c->stream));
     if (err_bwd) HIPCHK(c, hipMemcpyAsync(err_bwd, c->d_err_b, fb, hipMemcpyDeviceToHost, c->stream));
     if (dist) HIPCHK(c, hipMemcpyAsync(dist, c->d_dist, fb, hipMemcpyDeviceToHost, c->stream));
+    if (valid) HIPCHK(c, hipMemcpyAsync(valid, c->d_valid, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICELK_OK;
+}
+
+int icelk_fb_filter(icelk_t* h, const float* p0, const float* p0r, int n, float fb_threshold, float* dist,
+                    uint8_t* valid)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n < 0) FAIL(c, ICELK_EARG, "negative point count");
+    if (n > c->max_pts) FAIL(c, ICELK_ECAP, "more points than max_pts of icelk_create");
+    if (n == 0) return ICELK_OK;
+    if (!p0 || !p0r) FAIL(c, ICELK_EARG, "null point buffer");
+    HIPCHK(c, hipMemcpyAsync(c->d_p0, p0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_p0r, p0r, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    launch_fb_filter(c->stream, c->d_p0, c->d_p0r, n, fb_threshold, c->fb_dist_form, c->d_dist, c->d_valid);
+    int rc = check_launch(c, "fb_filter");
+    if (rc) return rc;
+    if (dist) HIPCHK(c, hipMemcpyAsync(dist, c->d_dist, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     if (valid) HIPCHK(c, hipMemcpyAsync(valid, c->d_valid, n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ICELK_OK;

@@ -32,6 +32,7 @@ struct LKParams {
     float min_eig_thr;
     float fb_thr;
     int margin;         // search-region margin R of the LDS-staged J tile
+    int dist_form;      // forward-backward distance: 0 = np.hypot on float32 (s1:330), 1 = (dx^2+dy^2)^0.5 (s0_1:99)
 };
 
 // kernel ids for the profiling table
@@ -160,6 +161,8 @@ void sort_keys_desc(hipStream_t s, DetectScratch& D, const unsigned long long* i
 void launch_emit_corners(hipStream_t s, const unsigned long long* keys, int n, int w, float* xy);
 
 // Segment bookkeeping (k_tracks.hip).
+void launch_fb_filter(hipStream_t s, const float* p0, const float* p0r, int n, float thr, int form, float* dist,
+                      uint8_t* valid);
 void launch_seg_init(hipStream_t s, const float* corners, int n, float* xy, uint8_t* alive, float* tracks,
                      int max_vert);
 // {alive tracks, features tracked so far} -> host_out[0..1] (pinned, 64-bit each)

@@ -301,8 +301,7 @@ __global__ __launch_bounds__(64) void k_lk(Pyramid PI, Pyramid PJ, LKBuffers B, 
             if (B.p_bwd) { B.p_bwd[2 * f] = r2.x; B.p_bwd[2 * f + 1] = r2.y; }
             if (B.st_bwd) B.st_bwd[f] = (uint8_t)r2.status;
             if (B.err_bwd) B.err_bwd[f] = r2.err;
-            const float ddx = fabsf(__fsub_rn(p0x, r2.x)), ddy = fabsf(__fsub_rn(p0y, r2.y));
-            const float d = sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
+            const float d = fb_distance(p0x, p0y, r2.x, r2.y, P.dist_form);
             if (B.dist) B.dist[f] = d;
             if (B.valid) B.valid[f] = d < P.fb_thr ? 1 : 0;
             if (B.seg_alive) seg_append(B, f, r1.x, r1.y, d, d < P.fb_thr);

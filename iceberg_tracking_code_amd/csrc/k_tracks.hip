@@ -6,7 +6,7 @@
 // tracker launch itself appends vertices and clears `alive` (lk_common.h seg_append), so extending a segment
 // costs no extra launch and nothing crosses PCIe.  Order-preserving compaction happens once, when a finished
 // segment is read out.
-#include "icelk_internal.h"
+#include "lk_common.h"
 
 namespace icelk {
 
@@ -131,7 +131,25 @@ __global__ __launch_bounds__(1024) void k_seg_gather(const uint8_t* __restrict__
     }
 }
 
+// the forward-backward filter of s1:329-333 on its own: the same device function the fused tracker launches end with
+__global__ void k_fb_filter(const float* __restrict__ p0, const float* __restrict__ p0r, int n, float thr, int form,
+                            float* __restrict__ dist, uint8_t* __restrict__ valid)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float d = lk::fb_distance(p0[2 * i], p0[2 * i + 1], p0r[2 * i], p0r[2 * i + 1], form);
+    dist[i] = d;
+    valid[i] = d < thr ? 1 : 0;
+}
+
 }  // namespace
+
+void launch_fb_filter(hipStream_t s, const float* p0, const float* p0r, int n, float thr, int form, float* dist,
+                      uint8_t* valid)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_fb_filter, dim3((n + 255) / 256), dim3(256), 0, s, p0, p0r, n, thr, form, dist, valid);
+}
 
 void launch_seg_init(hipStream_t s, const float* corners, int n, float* xy, uint8_t* alive, float* tracks,
                      int max_vert)

@@ -116,6 +116,18 @@ __device__ __forceinline__ void seg_append(const LKBuffers& B, int f, float x, f
     atomicAdd(&B.seg_tracked[f & 63], 1ull);
 }
 
+// Forward-backward distance of s1_lucaskanade_tracking.py:329-330: diff = abs(p0 - p0r) in float32, then
+// np.hypot on float32 = the C library's hypotf, which glibc evaluates as (float)sqrt((double)x*x + (double)y*y)
+// (both products exact in double, one rounding in the sum, one in the correctly rounded sqrt, one in the narrowing).
+// form 1 is the demo script's float32 expression (dx**2 + dy**2)**0.5 (s0_1_test_lucaskanade_tracking.py:99).
+__device__ __forceinline__ float fb_distance(float p0x, float p0y, float rx, float ry, int form)
+{
+    const float ddx = fabsf(__fsub_rn(p0x, rx)), ddy = fabsf(__fsub_rn(p0y, ry));
+    if (form == 1) return sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
+    const double x = (double)ddx, y = (double)ddy;
+    return (float)sqrt(__dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y)));
+}
+
 template <bool SMALL, int G>
 __device__ __forceinline__ long long sum_pick(int v)
 {

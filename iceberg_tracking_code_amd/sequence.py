@@ -28,7 +28,7 @@ def _decode(path):
 
 def track_image_sequence(imagelist, target_dir, track_len, track_len_sec, startlist=(0,), crop=None, mask=None,
                          mask_polygon=None, feature_params=None, lk_params=None, decode_threads=4, decode_ahead=6,
-                         gray_variant=3, device=0, on_segment=None, save=True):
+                         gray_variant=4, device=0, on_segment=None, save=True):
     """Track one day's photos.  Returns [(npz path, tracks (n, T+1, 2) f32, trackquality (n, T) f32)] of the
     segments that pass the time-gap rule, in order.
 

@@ -66,7 +66,7 @@ def run_reference_loop(frames, track_len, feature_params=None, lk_params=None, m
             p1, st, err = cv.calcOpticalFlowPyrLK(img0, img1, p0, None, **lk_params)
             p0r, st, err = cv.calcOpticalFlowPyrLK(img1, img0, p1, None, **lk_params)
             diff = abs(p0 - p0r).reshape(-1, 2)
-            dist = np.sqrt(diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1], dtype=np.float32)
+            dist = np.hypot(diff[:, 0], diff[:, 1])
             valid = dist < fb_threshold
             new_tracks, new_quality = [], []
             for tr, (x, y), ok, trq, d in zip(tracks, p1.reshape(-1, 2), valid, trackquality, dist):
@@ -191,7 +191,7 @@ class SegmentTracker:
         self.ctx.upload_gray(s, frame_gray)
         return self._step(s, wait)
 
-    def push_bgr(self, frame, wait=True, variant=3, crop=None):
+    def push_bgr(self, frame, wait=True, variant=4, crop=None):
         """`crop` = (left, top, right, bottom): the box of camtools.py:213-231, cut during the upload."""
         s = self._next_slot()
         self.ctx.upload_bgr(s, frame, variant, crop)

@@ -9,8 +9,14 @@
  * Conventions
  *   - every function returns ICELK_OK (0) or a negative ICELK_E* code; icelk_last_error() gives text.
  *   - the caller owns every host buffer; the library owns all device memory (frames, pyramids, points).
- *   - a handle is bound to one GPU and one HIP stream and is not thread-safe; use one handle per
- *     thread/process.  Multi-GPU = one process per GPU, one handle each (DESIGN.md "Multi-GPU").
+ *   - a handle is bound to one GPU and is not thread-safe; use one handle per thread/process.
+ *     Multi-GPU = one process per GPU, one handle each (DESIGN.md "Multi-GPU").
+ *   - a handle owns FOUR HIP streams: compute (tracker launches, segment bookkeeping; replaceable by the
+ *     caller's stream, icelk_set_stream), copy (icelk_upload_gray_async, icelk_build_pyramid_ahead), detection
+ *     (min-distance stage, sort, emit) and candidates (the corner kernel of icelk_seg_detect_prepare).  They are
+ *     ordered against each other by events inside the library; a call whose outputs are host buffers has
+ *     finished with them when it returns.  icelk_sync waits for ALL four: after it nothing of the handle
+ *     reads or writes any slot, mask or point buffer.
  *   - "slot" = a device-resident frame with its Gaussian pyramid.  Slots let the caller keep the
  *     previous frame (prev_gray = frame_gray, s1:450) and its pyramid on the GPU instead of
  *     rebuilding both pyramids in every cv2.calcOpticalFlowPyrLK call as OpenCV does.
@@ -46,6 +52,10 @@ typedef struct icelk_ctx icelk_t;
 /* fixed-point coefficient sets of cv2.cvtColor(COLOR_BGR2GRAY): OpenCV 3.x (14 bit), 4.x (15 bit) */
 #define ICELK_GRAY_CV3 3
 #define ICELK_GRAY_CV4 4
+/* forward-backward distance of icelk_track_fb / icelk_seg_track: np.hypot on float32 as s1:330 (default), or the
+ * float32 expression (dx**2 + dy**2)**0.5 of the demo script s0_1:99 */
+#define ICELK_FB_HYPOT 0
+#define ICELK_FB_SQRT 1
 
 #define ICELK_MAX_LEVELS 12 /* pyramid images per slot (maxLevel <= 11) */
 
@@ -60,6 +70,9 @@ int icelk_destroy(icelk_t* h);
 /* Run all work on the caller's HIP stream (hipStream_t as void*; NULL = the handle's own stream). */
 int icelk_set_stream(icelk_t* h, void* hip_stream);
 int icelk_sync(icelk_t* h);
+/* How the fused tracker calls form dist from |p0 - p0r| (ICELK_FB_HYPOT / ICELK_FB_SQRT); the two can differ in
+ * the last bit, which flips `valid` for a distance within one ulp of the threshold. */
+int icelk_set_fb_distance(icelk_t* h, int form);
 
 /* ---- frame ingest: replaces cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY) at s1:283,311 / s0_1:71,80 */
 /* host 8-bit gray image -> slot (level 0); invalidates the slot's pyramid. */
@@ -100,12 +113,18 @@ int icelk_pyrlk(icelk_t* h, int prev_slot, int next_slot, const float* prev_xy, 
                 int crit_type, int max_count, double epsilon, int flags, double min_eig_threshold);
 /* Fused forward + backward + distance test of s1:323-333 (one launch, pyramids built once):
  *   p1 = LK(slot0 -> slot1, p0);  p0r = LK(slot1 -> slot0, p1);
- *   dist = sqrt(dx^2 + dy^2) of |p0 - p0r|;  valid = dist < fb_threshold.
+ *   dist = np.hypot(|p0 - p0r|) on float32 (s1:329-330; see icelk_set_fb_distance);  valid = dist < fb_threshold.
  * Any output pointer may be NULL. */
 int icelk_track_fb(icelk_t* h, int slot0, int slot1, const float* p0, int n, int win_w, int win_h,
                    int max_level, int crit_type, int max_count, double epsilon, double min_eig_threshold,
                    float fb_threshold, float* p1, float* p0r, uint8_t* st_fwd, uint8_t* st_bwd,
                    float* err_fwd, float* err_bwd, float* dist, uint8_t* valid);
+
+/* The filter of s1:329-333 on its own, for callers of the plain icelk_pyrlk: diff = abs(p0 - p0r) in float32,
+ * dist = np.hypot(diff) (or the s0_1:99 form, icelk_set_fb_distance), valid = dist < fb_threshold.  Runs the very
+ * device function the fused launches end with.  dist / valid may be NULL. */
+int icelk_fb_filter(icelk_t* h, const float* p0, const float* p0r, int n, float fb_threshold, float* dist,
+                    uint8_t* valid);
 
 /* ---- detector: replaces cv2.goodFeaturesToTrack(frame_gray, mask=mask, **feature_params) s1:437 */
 /* Mask (s1:285-294) is uploaded once and reused; NULL clears it. */

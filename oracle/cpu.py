@@ -64,6 +64,9 @@ def lib():
                                    _u8p, _f32p, _f32p, _f32p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_double, C.c_double, C.c_float]
         L.orc_min_eig_map.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+        L.orc_set_fb_distance.argtypes = [C.c_int]
+        L.orc_fb_distance.argtypes = [C.c_float] * 4
+        L.orc_fb_distance.restype = C.c_float
         L.orc_good_features.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.c_int, _f32p, C.c_int, _i32p]
         L.orc_project_tracks.argtypes = [_f32p, C.c_int, C.c_int, C.POINTER(UtmCamera), C.POINTER(UtmFilter), _f64p,
@@ -102,6 +105,19 @@ def lk_stats(reset=True):
 
 def set_threads(n):
     return lib().orc_set_threads(int(n))
+
+
+def set_fb_distance(form):
+    """0 = np.hypot on float32 (s1:330, default), 1 = (dx**2 + dy**2)**0.5 in float32 (s0_1:99)."""
+    lib().orc_set_fb_distance(int(form))
+
+
+def fb_distance(p0, p0r):
+    """dist of s1:329-330 for (n, 2) float32 point arrays, one scalar call per point (for the known-answer test)."""
+    p0 = np.asarray(p0, np.float32).reshape(-1, 2)
+    p0r = np.asarray(p0r, np.float32).reshape(-1, 2)
+    f = lib().orc_fb_distance
+    return np.array([f(a[0], a[1], b[0], b[1]) for a, b in zip(p0, p0r)], np.float32)
 
 
 def bgr2gray(src, variant=3):

@@ -502,9 +502,19 @@ int orc_pyrlk(const uint8_t* prev, int prev_stride, const uint8_t* next, int nex
 /* ------------------------------------------------------------------------------------------
  * Forward-backward check of the reference loop (s1:323-333):
  *   p1 = LK(img0,img1,p0); p0r = LK(img1,img0,p1); dist = hypot(|p0-p0r|); valid = dist < 1
- * dist is computed as sqrtf(dx*dx + dy*dy) in float (the s0_1:99 form); np.hypot at s1:330 may
- * differ from it in the last bit, which only matters for a dist within 1 ULP of the threshold.
+ * diff = abs(p0 - p0r) in float32, dist = np.hypot(diff_x, diff_y) on float32 (s1:329-330): numpy calls the
+ * C library's hypotf, used here as it is (glibc evaluates it as (float)sqrt((double)x*x + (double)y*y));
+ * tests/test_oracle_kat.py pins it against numpy, including distances one ulp either side of 1.0.
+ * dist_form 1 = the demo script's float32 expression (dx**2 + dy**2)**0.5 (s0_1:99).
  * ---------------------------------------------------------------------------------------- */
+static int g_dist_form = 0;
+void orc_set_fb_distance(int form) { g_dist_form = form; }
+float orc_fb_distance(float p0x, float p0y, float rx, float ry)
+{
+    float dx = fabsf(p0x - rx), dy = fabsf(p0y - ry);
+    return g_dist_form == 1 ? sqrtf(dx * dx + dy * dy) : hypotf(dx, dy);
+}
+
 int orc_track_fb(const uint8_t* img0, int stride0, const uint8_t* img1, int stride1, int w, int h,
                  const float* p0, float* p1, float* p0r, uint8_t* st_fwd, uint8_t* st_bwd,
                  float* err_fwd, float* err_bwd, float* dist, uint8_t* valid, int n,
@@ -518,8 +528,7 @@ int orc_track_fb(const uint8_t* img0, int stride0, const uint8_t* img1, int stri
                    max_level, crit_type, max_count, epsilon, 0, min_eig_threshold);
     if (rc < 0) return rc;
     for (int i = 0; i < n; i++) {
-        float dx = fabsf(p0[2 * i] - p0r[2 * i]), dy = fabsf(p0[2 * i + 1] - p0r[2 * i + 1]);
-        dist[i] = sqrtf(dx * dx + dy * dy);
+        dist[i] = orc_fb_distance(p0[2 * i], p0[2 * i + 1], p0r[2 * i], p0r[2 * i + 1]);
         valid[i] = dist[i] < fb_threshold ? 1 : 0;
     }
     return rc;

@@ -25,12 +25,12 @@ def test_cv2_shaped_functions(orc, synth):
     rgb = synth.rgb_from_gray_seeded(321, 200, 10, -20, 8)
     gray = cv2.cvtColor(rgb, cv2.COLOR_BGR2GRAY)
     assert gray.dtype == np.uint8 and gray.shape == (200, 321)
-    assert np.array_equal(gray, orc.bgr2gray(rgb, 3))
+    assert np.array_equal(gray, orc.bgr2gray(rgb, 4))   # default = the 4.x coefficients (environment.yml:254)
     # the reference hands PIL's RGB arrays to COLOR_BGR2GRAY (s1:310-311): channel 0 gets the 0.114 weight
-    assert np.array_equal(cv2.cvtColor(rgb, cv2.COLOR_RGB2GRAY), orc.bgr2gray(rgb[:, :, ::-1].copy(), 3))
-    cv2.set_gray_variant(4)
-    assert np.array_equal(cv2.cvtColor(rgb, cv2.COLOR_BGR2GRAY), orc.bgr2gray(rgb, 4))
+    assert np.array_equal(cv2.cvtColor(rgb, cv2.COLOR_RGB2GRAY), orc.bgr2gray(rgb[:, :, ::-1].copy(), 4))
     cv2.set_gray_variant(3)
+    assert np.array_equal(cv2.cvtColor(rgb, cv2.COLOR_BGR2GRAY), orc.bgr2gray(rgb, 3))
+    cv2.set_gray_variant(4)
     a, b = synth.frame(400, 300, 0, 0, 5), synth.frame(400, 300, 200, 300, 5)
     mask = np.zeros_like(a)
     mask[:, 100:] = 255
@@ -206,3 +206,69 @@ def test_plain_c_caller(tmp_path):
     assert f[0] == "corners" and int(f[1]) == 200 and int(f[3]) > 150
     # the second frame samples the texture 300/256 px further right and 200/256 px further up: content moves the other way
     assert abs(float(f[5]) + 300 / 256.0) < 0.05 and abs(float(f[6]) - 200 / 256.0) < 0.05
+
+
+def test_sync_covers_the_candidate_stream(orc, synth):
+    """icelk_sync waits for all four streams of the handle, the candidate stream of icelk_seg_detect_prepare included:
+    after it every ingest path may overwrite the slot, and a later detection of that slot sees the NEW frame (the
+    prepared candidates of the old one are dropped)."""
+    from iceberg_tracking_code_amd import Context
+    import torch
+    w, h = 1024, 768
+    old = synth.frame(w, h, 0, 0, 21)
+    new = [synth.frame(w, h, 0, 0, 30 + k) for k in range(4)]
+    rgb = synth.rgb_from_gray_seeded(w, h, 0, 0, 9)
+    c = Context(w, h, n_slots=2, max_pts=1 << 16)
+    try:
+        want = [orc.good_features(f, 500, 0.01, 10, None, 10) for f in new]
+        want_rgb = orc.good_features(orc.bgr2gray(rgb, 4), 500, 0.01, 10, None, 10)
+        pin = c.host_alloc(w * h)
+        dev = torch.from_numpy(new[2]).cuda()
+        dev_rgb = torch.from_numpy(rgb).cuda()
+        torch.cuda.synchronize()
+        for path in range(6):
+            c.upload_gray(0, old)
+            for _ in range(3):
+                c.seg_detect_prepare(0, False, 10)     # candidate kernels queued on the fourth stream
+                c.upload_gray(1, old)
+                c.seg_detect_prepare(1, False, 10)
+            c.sync()
+            if path == 0:
+                c.upload_gray(0, new[0]); ref = want[0]
+            elif path == 1:
+                C.memmove(pin, new[1].ctypes.data, w * h)
+                c.upload_gray_async(0, pin, w, h, w); ref = want[1]
+            elif path == 2:
+                c.set_gray_device(0, dev.data_ptr(), w, h, w); ref = want[2]
+            elif path == 3:
+                c.upload_bgr(0, rgb, 4); ref = want_rgb
+            elif path == 4:
+                c.cvt_bgr_device(0, dev_rgb.data_ptr(), w, h, 3 * w, 4); ref = want_rgb
+            else:
+                c.synth_frame(0, w, h, 0, 0, 33); ref = want[3]
+            got = c.good_features(0, 500, 0.01, 10, False, 10)
+            assert np.array_equal(got, ref), path
+        c.host_free(pin)
+    finally:
+        c.close()
+
+
+def test_uncapped_detection_beyond_max_pts_is_an_error(synth):
+    """maxCorners=50_000_000 (s1:240) means "all of them": when more corners pass than the handle was created for, the
+    call fails with ICELK_ECAP instead of returning a silently shortened list."""
+    from iceberg_tracking_code_amd import Context, REF_FEATURE_PARAMS
+    from iceberg_tracking_code_amd._lib import IcelkError
+    img = synth.frame(640, 480, 0, 0, 4)
+    c = Context(640, 480, n_slots=1, max_pts=64)
+    try:
+        c.upload_gray(0, img)
+        with pytest.raises(IcelkError, match="-4"):
+            c.good_features(0, REF_FEATURE_PARAMS["maxCorners"], 0.007, 10, False, 10)
+        with pytest.raises(IcelkError, match="-4"):
+            c.good_features(0, 0, 0.007, 10, False, 10)
+        with pytest.raises(IcelkError, match="-4"):
+            c.seg_detect(0, 0, 0.007, 10, False, 10)
+        got = c.good_features(0, 64, 0.007, 10, False, 10)   # a real cap within the capacity is fine
+        assert got is not None and len(got) == 64
+    finally:
+        c.close()

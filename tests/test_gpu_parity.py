@@ -303,3 +303,38 @@ def test_topk_pruning_is_invisible(ctx, orc, synth, maxc, monkeypatch):
     exp = orc.good_features(img, maxc, 0.007, 10, mask, 10)
     assert np.array_equal(got, exp)
     ctx.set_mask(None)
+
+
+def test_fb_distance_is_numpy_hypot(ctx, orc, synth):
+    """s1:329-333 on the device: `dist = np.hypot(abs(p0 - p0r))` in float32 and `valid = dist < 1`, against numpy
+    itself -- on distances one ulp either side of 1.0, on pairs where the float32 sqrt form decides differently, and
+    on the dist / valid a fused tracker launch returns."""
+    from test_oracle_kat import fb_straddle_cases
+    from iceberg_tracking_code_amd.context import FB_HYPOT, FB_SQRT
+    dx, dy = fb_straddle_cases()
+    p0r = np.zeros((len(dx), 2), np.float32)
+    p0 = np.stack([dx, dy], 1)
+    p0[::2], p0r[::2] = p0r[::2].copy(), p0[::2].copy()
+    d = np.abs(p0 - p0r)
+    want = np.hypot(d[:, 0], d[:, 1])
+    dist, valid = ctx.fb_filter(p0, p0r, 1.0)
+    assert np.array_equal(dist.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(valid.astype(bool), want < 1) and 0 < valid.sum() < len(valid)
+    ctx.set_fb_distance(FB_SQRT)
+    try:
+        alt, avalid = ctx.fb_filter(p0, p0r, 1.0)
+    finally:
+        ctx.set_fb_distance(FB_HYPOT)
+    s = (d[:, 0] ** 2 + d[:, 1] ** 2) ** 0.5   # s0_1:99
+    assert np.array_equal(alt.view(np.uint32), s.view(np.uint32)) and np.array_equal(avalid.astype(bool), s < 1)
+    assert (avalid != valid).sum() > 20
+    # the epilogue of the fused launch is the same function of the p0 / p0r it returns
+    img0, img1 = _pair(synth, 640, 480, 600, 420)
+    pts = orc.good_features(img0, 3000, 0.005, 5, blockSize=5).reshape(-1, 2)
+    ctx.upload_gray(0, img0)
+    ctx.upload_gray(1, img1)
+    g = ctx.track_fb(0, 1, pts, (21, 21), 3, CRIT_DEFAULT)
+    dd = np.abs(pts - g["p0r"])
+    hyp = np.hypot(dd[:, 0], dd[:, 1])
+    assert np.array_equal(g["dist"].view(np.uint32), hyp.view(np.uint32))
+    assert np.array_equal(g["valid"].astype(bool), hyp < 1)

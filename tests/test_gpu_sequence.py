@@ -37,7 +37,7 @@ def test_folder_of_jpegs_equals_reference_loop_on_oracle(orc, synth, tmp_path):
     # the same on the CPU: PIL decode, numpy crop, oracle gray / mask / loop
     decoded = [np.array(Image.open(p)) for p in names]
     cropped = [np.ascontiguousarray(d[crop[1]:h - crop[3], crop[0]:w - crop[2]]) for d in decoded]
-    gray = [orc.bgr2gray(c, 3) for c in cropped]
+    gray = [orc.bgr2gray(c, 4) for c in cropped]   # the default coefficient set (environment.yml:254: opencv 4.9)
     mask = orc.polygon_mask(poly, crop[0], crop[1], gray[0].shape[1], gray[0].shape[0])
     ref = run_reference_loop(gray, T, fp, lk, mask=mask, cv=OracleCv(orc))
     want = []

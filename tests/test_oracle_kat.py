@@ -177,3 +177,70 @@ def test_golden_vectors(orc):
     assert np.array_equal(st, g["st"]) and np.array_equal(er.view(np.uint32), g["err"].view(np.uint32))
     assert np.array_equal(orc.good_features(g["img0"], 0, 0.01, 6, None, 5), g["corners"])
     assert np.array_equal(orc.pyrdown(g["img0"]), g["down"])
+
+
+def fb_straddle_cases():
+    """(dx, dy) float32 pairs around the unit circle whose np.hypot is 1 - ulp, 1, 1 + ulp, plus pairs where the
+    float32 expression sqrt(dx*dx + dy*dy) lands on the other side of 1.0 than np.hypot (s1:330 vs s0_1:99)."""
+    rng = np.random.RandomState(7)
+    t = rng.uniform(0, np.pi / 2, 400000)
+    dx0, dy = np.cos(t).astype(np.float32), np.sin(t).astype(np.float32)
+    one = np.float32(1)
+    xs, ys = [], []
+    for bump in (0, 1, -1, 2, -2):   # neighbouring float32 values of dx
+        cand = (dx0.view(np.int32) + bump).view(np.float32)
+        h = np.hypot(cand, dy)
+        s = np.sqrt(cand * cand + dy * dy, dtype=np.float32)
+        sel = np.zeros(len(t), bool)
+        for tgt in (np.nextafter(one, np.float32(0)), one, np.nextafter(one, np.float32(2))):
+            sel[np.nonzero(h == tgt)[0][:40]] = True
+        sel[np.nonzero((h < one) != (s < one))[0][:200]] = True
+        xs.append(cand[sel])
+        ys.append(dy[sel])
+    return np.concatenate(xs), np.concatenate(ys)
+
+
+def test_fb_distance_is_numpy_hypot_on_float32(orc):
+    """s1:329-333: `valid = np.hypot(|p0 - p0r|) < 1` -- the oracle's distance against numpy itself, on values one ulp
+    either side of the threshold and on pairs where the float32 sqrt form would decide differently."""
+    dx, dy = fb_straddle_cases()
+    assert len(dx) > 300
+    p0r = np.zeros((len(dx), 2), np.float32)   # a zero origin keeps p0 - p0r exact
+    p0 = np.stack([dx, dy], 1)
+    p0[::2], p0r[::2] = p0r[::2].copy(), p0[::2].copy()   # both signs of the difference
+    d = np.abs(p0 - p0r)
+    want = np.hypot(d[:, 0], d[:, 1])
+    assert want.dtype == np.float32
+    one = np.float32(1)
+    for tgt in (np.nextafter(one, np.float32(0)), one, np.nextafter(one, np.float32(2))):
+        assert (want == tgt).any()
+    orc.set_fb_distance(0)
+    got = orc.fb_distance(p0, p0r)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    orc.set_fb_distance(1)
+    alt = orc.fb_distance(p0, p0r)
+    orc.set_fb_distance(0)
+    assert np.array_equal(alt.view(np.uint32), ((d[:, 0] ** 2 + d[:, 1] ** 2) ** 0.5).view(np.uint32))   # s0_1:99
+    assert int(((alt < 1) != (want < 1)).sum()) > 20   # the two forms really do decide differently at the threshold
+
+
+def test_box_sums_of_the_covariance_planes_are_exact_in_double():
+    """cornerMinEigenVal's boxFilter keeps double sums of float32 products.  For 8-bit input every such
+    product lies in [2^-30, 2^-4] with a 24-bit mantissa, so any sum of <= 32x32 of them is exact in double: sliding
+    (OpenCV's RowSum / ColumnSum) and direct summation (oracle, kernels) give the same float32 -- the summation order is
+    not a parity risk."""
+    import math
+    rng = np.random.RandomState(11)
+    for bs in (3, 5, 7, 10, 16, 32):
+        scale = np.float32(1.0 / (4.0 * bs * 255.0))
+        # derivative values as the Sobel passes produce them: integer combinations of pixels times the scale
+        dx = (rng.randint(-1020, 1021, 4096).astype(np.float32) * scale).astype(np.float32)
+        dy = (rng.randint(-1020, 1021, 4096).astype(np.float32) * scale).astype(np.float32)
+        for plane in (dx * dx, dx * dy, dy * dy):
+            assert plane.dtype == np.float32
+            win = plane[:bs * bs].astype(np.float64)
+            direct = 0.0
+            for v in win:
+                direct += v
+            sliding = float(np.cumsum(plane.astype(np.float64))[bs * bs - 1])
+            assert direct == math.fsum(win.tolist()) == sliding
