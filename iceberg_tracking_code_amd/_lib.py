@@ -28,6 +28,7 @@ SIGNATURES = {
     "icelk_set_stream": (C.c_int, [handle_p, vp]),
     "icelk_sync": (C.c_int, [handle_p]),
     "icelk_set_fb_distance": (C.c_int, [handle_p, C.c_int]),
+    "icelk_set_lk_kernel": (C.c_int, [handle_p, C.c_int]),
     "icelk_upload_gray": (C.c_int, [handle_p, C.c_int, u8p, C.c_int, C.c_int, C.c_int]),
     "icelk_upload_bgr": (C.c_int, [handle_p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "icelk_set_gray_device": (C.c_int, [handle_p, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
@@ -70,6 +71,7 @@ SIGNATURES = {
     "icelk_seg_read": (C.c_int, [handle_p, f32p, f32p, C.c_int, C.c_int, i32p, i32p]),
     "icelk_prof_enable": (C.c_int, [handle_p, C.c_int]),
     "icelk_prof_reset": (C.c_int, [handle_p]),
+    "icelk_prof_iterations": (C.c_int, [handle_p, C.POINTER(C.c_uint32), C.c_int, i32p]),
     "icelk_prof_count": (C.c_int, []),
     "icelk_prof_name": (C.c_char_p, [C.c_int]),
     "icelk_prof_get": (C.c_int, [handle_p, C.c_int, i32p, f64p]),

@@ -17,6 +17,8 @@ OPTFLOW_USE_INITIAL_FLOW = 4
 OPTFLOW_LK_GET_MIN_EIGENVALS = 8
 GRAY_CV3 = 3
 GRAY_CV4 = 4
+LK_GENERIC_KERNEL = 0x100
+LK_MULTI_PER_WAVE = 0x200
 FB_HYPOT = 0
 FB_SQRT = 1
 
@@ -81,6 +83,10 @@ class Context:
 
     def sync(self):
         self._ck(self._lib.icelk_sync(self._h))
+
+    def set_lk_kernel(self, which):
+        """0 = default, LK_GENERIC_KERNEL or LK_MULTI_PER_WAVE: the three tracker kernels give identical results."""
+        self._ck(self._lib.icelk_set_lk_kernel(self._h, int(which)))
 
     def set_fb_distance(self, form):
         """FB_HYPOT (np.hypot on float32, s1:330; default) or FB_SQRT ((dx**2+dy**2)**0.5, s0_1:99)."""
@@ -289,6 +295,19 @@ class Context:
 
     def prof_reset(self):
         self._ck(self._lib.icelk_prof_reset(self._h))
+
+    def prof_iterations(self):
+        """(forward, backward) LK iteration counts per feature of the latest tracker call made while profiling was on;
+        tracks that were already dead are left out."""
+        n = C.c_int(0)
+        self._ck(self._lib.icelk_prof_iterations(self._h, None, 0, C.byref(n)))
+        buf = np.zeros(max(n.value, 1), np.uint32)
+        if n.value:
+            self._ck(self._lib.icelk_prof_iterations(self._h, buf.ctypes.data_as(C.POINTER(C.c_uint32)), n.value,
+                                                     C.byref(n)))
+        buf = buf[:n.value]
+        buf = buf[buf != 0xffffffff]
+        return (buf & 0xffff).astype(np.int64), (buf >> 16).astype(np.int64)
 
     def prof_table(self):
         out = {}

@@ -90,6 +90,14 @@ struct Ctx {
     bool seg_ready_pending = false;   // ... and the compute stream has not been told to wait for it yet
     bool use_order = true;                 // ICELK_NO_ORDER=1 launches in detector order (A/B measurements)
     int fb_dist_form = ICELK_FB_HYPOT;     // icelk_set_fb_distance
+    int lk_kernel_flags = 0;               // icelk_set_lk_kernel: ICELK_FLAG_GENERIC_KERNEL / _ONE_PER_WAVE or 0
+    // diagnostics: ICELK_LK_STAMPS=<file> records entry / exit time and placement of every workgroup of the LAST
+    // segment tracker launch and writes them to the file when the handle is destroyed (tools/lk_stamps.py reads it)
+    uint32_t* d_iters = nullptr;   // per-feature iteration counts of the latest tracker launch (while profiling is on)
+    int iters_n = 0;
+    unsigned long long* d_stamps = nullptr;
+    size_t stamps_cap = 0;     // workgroups
+    std::string stamps_path;
     unsigned long long* d_tracked = nullptr;   // 64 sharded counters
     unsigned long long* h_seg = nullptr;   // pinned: {alive tracks, features tracked}
     float *d_out_tracks = nullptr, *d_out_quality = nullptr;
@@ -307,7 +315,16 @@ static int make_lk_params(Ctx* c, int w, int h, int win_w, int win_h, int max_le
     else epsilon = std::min(std::max(epsilon, 0.), 10.);
     P->max_count = max_count;
     P->eps2 = epsilon * epsilon;
-    P->flags = flags;
+    // A float evaluation of dx*dx + dy*dy is within 2^-22 (relative) of the double one OpenCV compares with eps^2;
+    // outside a 2^-20 band around eps^2 it decides, inside the exact form runs (k_lk_multi.hip)
+    if (P->eps2 < 1e-30) {
+        P->eps2_lo = -1.f;
+        P->eps2_hi = INFINITY;
+    } else {
+        P->eps2_lo = nextafterf((float)(P->eps2 * (1.0 - 1.0 / (1 << 20))), -INFINITY);
+        P->eps2_hi = nextafterf((float)(P->eps2 * (1.0 + 1.0 / (1 << 20))), INFINITY);
+    }
+    P->flags = flags | c->lk_kernel_flags;
     P->min_eig_thr = (float)min_eig_thr;
     P->fb_thr = fb_thr;
     P->margin = 6;
@@ -342,6 +359,17 @@ static void destroy_ctx(Ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     prof_drain(c);
+    if (c->d_stamps) {
+        std::vector<unsigned long long> hs(3 * c->stamps_cap);
+        if (hipMemcpy(hs.data(), c->d_stamps, hs.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* f = fopen(c->stamps_path.c_str(), "wb")) {
+                fwrite(hs.data(), 8, hs.size(), f);
+                fclose(f);
+            }
+        }
+        hipFree(c->d_stamps);
+    }
+    if (c->d_iters) hipFree(c->d_iters);
     for (auto& s : c->slots) {
         if (s.base) hipFree(s.base);
         if (s.ready) hipEventDestroy(s.ready);
@@ -662,6 +690,15 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
         B.seg_vert = c->seg_vert;
         B.seg_max_vert = kMaxVert;
         B.seg_tracked = c->d_tracked;
+        if (c->prof) {
+            B.iters = c->d_iters;
+            c->iters_n = c->seg_upper;
+            hipMemsetAsync(c->d_iters, 0xff, sizeof(uint32_t) * (size_t)c->seg_upper, c->stream);   // dead tracks stay ~0
+        }
+        if (c->d_stamps) {
+            B.stamps = c->d_stamps;
+            hipMemsetAsync(c->d_stamps, 0, 3 * c->stamps_cap * 8, c->stream);
+        }
         {
             ProfScope p(c, K_LK_FB);
             rc = launch_lk(c->stream, pyramid_of(s0), pyramid_of(s1), B, c->seg_upper, P, true);
@@ -803,6 +840,16 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &c->d_out_quality, np * (kMaxVert - 1))))
         return fail(rc);
     c->use_order = getenv("ICELK_NO_ORDER") == nullptr;
+    if ((rc = dmalloc(c, &c->d_iters, (size_t)max_pts))) return fail(rc);
+    if (const char* sp = getenv("ICELK_LK_STAMPS")) {
+        c->stamps_path = sp;
+        c->stamps_cap = (size_t)max_pts + 8;
+        if ((rc = dmalloc(c, &c->d_stamps, 3 * c->stamps_cap))) return fail(rc);
+    }
+    if (const char* k = getenv("ICELK_LK_KERNEL")) {   // A/B measurements: "generic" | "multi" (default: one feature per wave)
+        if (!strcmp(k, "generic")) c->lk_kernel_flags = ICELK_FLAG_GENERIC_KERNEL;
+        else if (!strcmp(k, "multi")) c->lk_kernel_flags = ICELK_FLAG_MULTI_PER_WAVE;
+    }
     activate_eig_out(c, 0);
     if (hipMemset(c->d_tracked, 0, 64 * 8) != hipSuccess) {
         c->err = "hipMemset failed";
@@ -840,6 +887,16 @@ int icelk_sync(icelk_t* h)
     HIPCHK(c, hipStreamSynchronize(c->eig_stream));
     HIPCHK(c, hipStreamSynchronize(c->det_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICELK_OK;
+}
+
+int icelk_set_lk_kernel(icelk_t* h, int which)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    if (which != 0 && which != ICELK_FLAG_GENERIC_KERNEL && which != ICELK_FLAG_MULTI_PER_WAVE)
+        FAIL(c, ICELK_EARG, "bad kernel selector");
+    c->lk_kernel_flags = which;
     return ICELK_OK;
 }
 
@@ -1097,6 +1154,7 @@ int icelk_pyrlk(icelk_t* h, int prev_slot, int next_slot, const float* prev_xy, 
     B.p_fwd = c->d_p1;
     B.st_fwd = c->d_st_f;
     B.err_fwd = c->d_err_f;
+    if (c->prof) { B.iters = c->d_iters; c->iters_n = n; }
     {
         ProfScope p(c, K_LK);
         rc = launch_lk(c->stream, pyramid_of(s0), pyramid_of(s1), B, n, P, false);
@@ -1147,6 +1205,7 @@ int icelk_track_fb(icelk_t* h, int slot0, int slot1, const float* p0, int n, int
     B.err_bwd = c->d_err_b;
     B.dist = c->d_dist;
     B.valid = c->d_valid;
+    if (c->prof) { B.iters = c->d_iters; c->iters_n = n; }
     {
         ProfScope p(c, K_LK_FB);
         rc = launch_lk(c->stream, pyramid_of(s0), pyramid_of(s1), B, n, P, true);
@@ -1642,6 +1701,21 @@ int icelk_prof_reset(icelk_t* h)
     for (int i = 0; i < K_COUNT_; i++) {
         c->prof_launches[i] = 0;
         c->prof_ms[i] = 0;
+    }
+    return ICELK_OK;
+}
+
+int icelk_prof_iterations(icelk_t* h, uint32_t* host_out, int cap, int* out_n)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!out_n || cap < 0 || (cap > 0 && !host_out)) FAIL(c, ICELK_EARG, "bad output buffer");
+    *out_n = c->iters_n;
+    if (host_out && cap > 0 && c->iters_n > 0) {
+        const int n = c->iters_n < cap ? c->iters_n : cap;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(host_out, c->d_iters, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
     }
     return ICELK_OK;
 }

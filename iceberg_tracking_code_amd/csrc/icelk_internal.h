@@ -32,6 +32,7 @@ struct LKParams {
     float min_eig_thr;
     float fb_thr;
     int margin;         // search-region margin R of the LDS-staged J tile
+    float eps2_lo, eps2_hi;   // float values below / above which (double)dx*dx + (double)dy*dy <= eps2 is decided
     int dist_form;      // forward-backward distance: 0 = np.hypot on float32 (s1:330), 1 = (dx^2+dy^2)^0.5 (s0_1:99)
 };
 
@@ -102,6 +103,10 @@ struct LKBuffers {
     float* seg_quality;          // [track][max_vert-1]
     int seg_vert, seg_max_vert;  // vertex written by this launch
     unsigned long long* seg_tracked;   // 64 sharded counters: features tracked (for throughput accounting)
+    // diagnostics (ICELK_LK_STAMPS=<file>): per workgroup {s_memtime at entry, at exit, HW_ID | XCC_ID << 32}
+    unsigned long long* stamps;
+    // measurement (icelk_prof_enable): LK iterations each feature ran, forward pass in the low half, backward in the high
+    uint32_t* iters;
 };
 size_t lk_lds_bytes(const LKParams& P);
 int launch_lk(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,

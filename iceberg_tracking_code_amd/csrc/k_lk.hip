@@ -27,6 +27,8 @@ namespace icelk {
 
 bool launch_lk_fast(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
                     bool fb);  // k_lk_fast.hip
+bool launch_lk_multi(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
+                     bool fb);  // k_lk_multi.hip
 
 namespace {
 
@@ -107,6 +109,7 @@ __device__ __forceinline__ TrackResult track_point(const Pyramid& PI, const Pyra
     TrackResult R;
     R.status = 1;
     R.err = 0.f;
+    R.iters = 0;
     float sx = 0.f, sy = 0.f;  // the stored nextPts value
 
     for (int level = P.top_level; level >= 0; level--) {
@@ -204,6 +207,7 @@ __device__ __forceinline__ TrackResult track_point(const Pyramid& PI, const Pyra
                 if (level == 0) R.status = 0;
                 break;
             }
+            R.iters++;
             if (!staged || inx < jx0 || inx > jx0 + 2 * P.margin || iny < jy0 || iny > jy0 + 2 * P.margin) {
                 jx0 = inx - P.margin; jy0 = iny - P.margin;
                 __syncthreads();
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(64) void k_lk(Pyramid PI, Pyramid PJ, LKBuffers B, 
         if (B.p_fwd) { B.p_fwd[2 * f] = r1.x; B.p_fwd[2 * f + 1] = r1.y; }
         if (B.st_fwd) B.st_fwd[f] = (uint8_t)r1.status;
         if (B.err_fwd) B.err_fwd[f] = r1.err;
+        if (B.iters && !FB) B.iters[f] = (uint32_t)r1.iters;
     }
     if (FB) {
         const TrackResult r2 = track_point<PPL>(PJ, PI, r1.x, r1.y, false, 0.f, 0.f, P, lds, lane);
@@ -301,6 +306,7 @@ __global__ __launch_bounds__(64) void k_lk(Pyramid PI, Pyramid PJ, LKBuffers B, 
             if (B.p_bwd) { B.p_bwd[2 * f] = r2.x; B.p_bwd[2 * f + 1] = r2.y; }
             if (B.st_bwd) B.st_bwd[f] = (uint8_t)r2.status;
             if (B.err_bwd) B.err_bwd[f] = r2.err;
+            if (B.iters) B.iters[f] = (uint32_t)r1.iters | ((uint32_t)r2.iters << 16);
             const float d = fb_distance(p0x, p0y, r2.x, r2.y, P.dist_form);
             if (B.dist) B.dist[f] = d;
             if (B.valid) B.valid[f] = d < P.fb_thr ? 1 : 0;
@@ -330,6 +336,12 @@ int launch_lk(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers
               bool fb)
 {
     if (n <= 0) return ICELK_OK;
+    // specialised windows: one feature per wave (k_lk_fast.hip) by default; ICELK_FLAG_MULTI_PER_WAVE selects the
+    // several-features-per-wave form (k_lk_multi.hip: a third fewer vector instructions per feature, but 2-3 waves per
+    // SIMD instead of 4 -- measured slower at 21x21, profiles/r02_lk_kernels.txt; kept as a third statement of the
+    // arithmetic and for window sizes / chips where the balance tips)
+    if ((P.flags & ICELK_FLAG_MULTI_PER_WAVE) && !(P.flags & ICELK_FLAG_GENERIC_KERNEL) && launch_lk_multi(s, I, J, B, n, P, fb))
+        return ICELK_OK;
     if (!(P.flags & ICELK_FLAG_GENERIC_KERNEL) && launch_lk_fast(s, I, J, B, n, P, fb)) return ICELK_OK;
     const int npx = P.win_w * P.win_h;
     const int ppl = (npx + 63) / 64;

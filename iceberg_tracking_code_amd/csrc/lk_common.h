@@ -36,6 +36,7 @@ struct TrackResult {
     float x, y;
     float err;
     int status;
+    int iters;   // iterations run (measurement)
 };
 
 // 64-lane integer sum through the DPP network (no LDS traffic): row prefix sums with row_shr 1/2/4/8,
@@ -126,6 +127,17 @@ __device__ __forceinline__ float fb_distance(float p0x, float p0y, float rx, flo
     if (form == 1) return sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
     const double x = (double)ddx, y = (double)ddy;
     return (float)sqrt(__dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y)));
+}
+
+// diagnostics: when and where a workgroup ran (lane 0 calls it; B.stamps is null outside diagnostic runs)
+__device__ __forceinline__ void stamp(const LKBuffers& B, int which)
+{
+    if (!B.stamps) return;
+    unsigned long long* s = B.stamps + 3 * (size_t)blockIdx.x;
+    s[which] = __builtin_amdgcn_s_memtime();
+    if (which == 0)
+        s[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+               ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 32);
 }
 
 template <bool SMALL, int G>

@@ -49,6 +49,9 @@ typedef struct icelk_ctx icelk_t;
 #define ICELK_FLAG_MIN_EIGENVALS 8
 /* testing aid: force the window-size-generic LK kernel where a specialised one exists (same results) */
 #define ICELK_FLAG_GENERIC_KERNEL 0x100
+/* the several-features-per-wave form of the specialised kernels (k_lk_multi.hip) instead of the default
+ * one-feature-per-wave form: fewer instructions per feature, lower occupancy; same results */
+#define ICELK_FLAG_MULTI_PER_WAVE 0x200
 /* fixed-point coefficient sets of cv2.cvtColor(COLOR_BGR2GRAY): OpenCV 3.x (14 bit), 4.x (15 bit) */
 #define ICELK_GRAY_CV3 3
 #define ICELK_GRAY_CV4 4
@@ -70,6 +73,9 @@ int icelk_destroy(icelk_t* h);
 /* Run all work on the caller's HIP stream (hipStream_t as void*; NULL = the handle's own stream). */
 int icelk_set_stream(icelk_t* h, void* hip_stream);
 int icelk_sync(icelk_t* h);
+/* Testing / measurement aid: which of the three bit-identical tracker kernels every LK call of this handle uses:
+ * 0 = the default choice, ICELK_FLAG_GENERIC_KERNEL, or ICELK_FLAG_MULTI_PER_WAVE. */
+int icelk_set_lk_kernel(icelk_t* h, int which);
 /* How the fused tracker calls form dist from |p0 - p0r| (ICELK_FB_HYPOT / ICELK_FB_SQRT); the two can differ in
  * the last bit, which flips `valid` for a distance within one ulp of the threshold. */
 int icelk_set_fb_distance(icelk_t* h, int form);
@@ -228,6 +234,10 @@ int icelk_grid_bin(icelk_t* h, const double* x, const double* y, const double* u
 /* Per-kernel HIP-event timing on the handle's stream (bench.py's roofline leg). */
 int icelk_prof_enable(icelk_t* h, int on);
 int icelk_prof_reset(icelk_t* h);
+/* LK iterations every feature of the latest tracker call ran while profiling was enabled: forward pass in the low 16
+ * bits, backward pass in the high 16 (0xffffffff = a track that was already dead); *out_n = features of that call.
+ * The iterations-per-feature histogram of bench.py comes from here. */
+int icelk_prof_iterations(icelk_t* h, uint32_t* host_out, int cap, int* out_n);
 int icelk_prof_count(void);
 const char* icelk_prof_name(int kernel_id);
 int icelk_prof_get(icelk_t* h, int kernel_id, int* launches, double* total_ms);

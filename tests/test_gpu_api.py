@@ -213,7 +213,14 @@ def test_sync_covers_the_candidate_stream(orc, synth):
     after it every ingest path may overwrite the slot, and a later detection of that slot sees the NEW frame (the
     prepared candidates of the old one are dropped)."""
     from iceberg_tracking_code_amd import Context
-    import torch
+    hip = C.CDLL("libamdhip64.so")   # the runtime libicelk.so itself runs on: plain device buffers, no torch
+
+    def to_device(a):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(a.nbytes)) == 0
+        assert hip.hipMemcpy(p, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), 1) == 0   # hipMemcpyHostToDevice
+        return p
+
     w, h = 1024, 768
     old = synth.frame(w, h, 0, 0, 21)
     new = [synth.frame(w, h, 0, 0, 30 + k) for k in range(4)]
@@ -223,9 +230,7 @@ def test_sync_covers_the_candidate_stream(orc, synth):
         want = [orc.good_features(f, 500, 0.01, 10, None, 10) for f in new]
         want_rgb = orc.good_features(orc.bgr2gray(rgb, 4), 500, 0.01, 10, None, 10)
         pin = c.host_alloc(w * h)
-        dev = torch.from_numpy(new[2]).cuda()
-        dev_rgb = torch.from_numpy(rgb).cuda()
-        torch.cuda.synchronize()
+        dev, dev_rgb = to_device(new[2]), to_device(rgb)
         for path in range(6):
             c.upload_gray(0, old)
             for _ in range(3):
@@ -239,16 +244,19 @@ def test_sync_covers_the_candidate_stream(orc, synth):
                 C.memmove(pin, new[1].ctypes.data, w * h)
                 c.upload_gray_async(0, pin, w, h, w); ref = want[1]
             elif path == 2:
-                c.set_gray_device(0, dev.data_ptr(), w, h, w); ref = want[2]
+                c.set_gray_device(0, dev.value, w, h, w); ref = want[2]
             elif path == 3:
                 c.upload_bgr(0, rgb, 4); ref = want_rgb
             elif path == 4:
-                c.cvt_bgr_device(0, dev_rgb.data_ptr(), w, h, 3 * w, 4); ref = want_rgb
+                c.cvt_bgr_device(0, dev_rgb.value, w, h, 3 * w, 4); ref = want_rgb
             else:
                 c.synth_frame(0, w, h, 0, 0, 33); ref = want[3]
             got = c.good_features(0, 500, 0.01, 10, False, 10)
             assert np.array_equal(got, ref), path
         c.host_free(pin)
+        c.sync()
+        hip.hipFree(dev)
+        hip.hipFree(dev_rgb)
     finally:
         c.close()
 

@@ -177,7 +177,8 @@ def test_good_features_mask_and_none(ctx, orc, synth):
 
 @pytest.mark.parametrize("win,maxlevel", [((21, 21), 3), ((31, 31), 5), ((35, 35), 4), ((15, 15), 2)])
 def test_specialised_equals_generic_kernel(ctx, orc, synth, win, maxlevel):
-    """k_lk_fast (compile-time window) and k_lk (generic) must agree bit for bit, borders included."""
+    """k_lk_fast (one feature per wave, the default), k_lk_multi (several per wave) and k_lk (generic) must agree bit for
+    bit, borders included -- also through the fused forward+backward launch, with every criteria form."""
     w, h = 640, 480
     img0, img1 = _pair(synth, w, h, -700, 555)
     rng = np.random.RandomState(win[0])
@@ -186,10 +187,27 @@ def test_specialised_equals_generic_kernel(ctx, orc, synth, win, maxlevel):
     ctx.upload_gray(1, img1)
     a = ctx.pyrlk(0, 1, pts, None, win, maxlevel, CRIT_DEFAULT, 0)
     b = ctx.pyrlk(0, 1, pts, None, win, maxlevel, CRIT_DEFAULT, 0x100)
+    c = ctx.pyrlk(0, 1, pts, None, win, maxlevel, CRIT_DEFAULT, 0x200)
     q = orc.pyrlk(img0, img1, pts, None, win, maxlevel, CRIT_DEFAULT)
-    for x, y, z in zip(a, b, q):
+    for x, y, v, z in zip(a, b, c, q):
         assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+        assert np.array_equal(x.view(np.uint8), v.view(np.uint8))
         assert np.array_equal(x.view(np.uint8), z.view(np.uint8))
+    # numbers of points that do not fill the last wave, criteria that end on the count / on a loose or zero epsilon
+    from iceberg_tracking_code_amd.context import LK_GENERIC_KERNEL, LK_MULTI_PER_WAVE
+    for npts, crit in ((1, CRIT_REF), (2, (1, 4, 0.0)), (3, (2, 0, 0.5)), (5, (3, 7, 0.0)), (1499, (3, 100, 1e-9)),
+                       (6, (3, 0, 0.03))):
+        got = {}
+        for which in (0, LK_GENERIC_KERNEL, LK_MULTI_PER_WAVE):
+            ctx.set_lk_kernel(which)
+            try:
+                got[which] = ctx.track_fb(0, 1, pts[:npts], win, maxlevel, crit)
+            finally:
+                ctx.set_lk_kernel(0)
+        r = orc.track_fb(img0, img1, pts[:npts], win, maxlevel, crit)
+        for which, g in got.items():
+            for k in ("p1", "p0r", "err_fwd", "err_bwd", "dist", "st_fwd", "st_bwd", "valid"):
+                assert np.array_equal(g[k].view(np.uint8), r[k].view(np.uint8)), (which, npts, crit, k)
 
 
 def test_large_motion_restage(ctx, orc, synth):
