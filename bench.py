@@ -202,7 +202,8 @@ def main():
         if not host:
             # the following frame is resident too: its detection (if it is a detection frame) may start now
             tracker.push_slot(order[i], wait=False, next_slot=order[i + 1] if i + 1 < W + K else None,
-                              next2_slot=order[i + 2] if i + 2 < W + K else None)
+                              next2_slot=order[i + 2] if i + 2 < W + K else None,
+                              next3_slot=order[i + 3] if i + 3 < W + K else None)
             return
         if i + 2 < W + K:   # frames i+1, i+2 are crossing PCIe while frame i is tracked
             tracker.prefetch_pinned(pinned[order[i + 2]], w)

@@ -261,6 +261,14 @@ class Context:
         self._ck(self._lib.icelk_seg_detect_finish(self._h, int(maxCorners), C.byref(n)))
         return n.value
 
+    def seg_detect_stage(self, maxCorners):
+        n = C.c_int(0)
+        self._ck(self._lib.icelk_seg_detect_stage(self._h, int(maxCorners), C.byref(n)))
+        return n.value
+
+    def seg_switch(self):
+        self._ck(self._lib.icelk_seg_switch(self._h))
+
     def seg_track(self, slot_prev, slot_next, winSize=(21, 21), maxLevel=3, criteria=DEFAULT_CRITERIA,
                   minEigThreshold=1e-4, fb_threshold=1.0, wait=True):
         t, cnt, eps = _criteria(criteria)

@@ -81,6 +81,7 @@ struct Ctx {
         float* live = nullptr;      // (max_pts,2) current position of every track of the segment
         uint8_t* alive = nullptr;   // 1 while the track survives
         int* order = nullptr;       // spatial launch order of the segment's tracks (k_seg_order)
+        int* order_border = nullptr;   // 1 int: leading entries of `order` that are border features
         float* tracks = nullptr;    // [track][kMaxVert][2]
         float* quality = nullptr;   // [track][kMaxVert-1]
         hipEvent_t used = nullptr;  // last launch on the compute stream that touches this set
@@ -89,6 +90,10 @@ struct Ctx {
     hipEvent_t seg_ready = nullptr;   // the current set has been initialised (detection stream)
     bool seg_ready_pending = false;   // ... and the compute stream has not been told to wait for it yet
     bool use_order = true;                 // ICELK_NO_ORDER=1 launches in detector order (A/B measurements)
+    // features this close to the frame border count as slow (launched first): from the window and pyramid depth of the
+    // latest tracker call; ICELK_NO_BORDER_FIRST=1 turns the class off
+    int border_px = (10 + 6 + 2) << 2;
+    bool border_first = true;
     int fb_dist_form = ICELK_FB_HYPOT;     // icelk_set_fb_distance
     int lk_kernel_flags = 0;               // icelk_set_lk_kernel: ICELK_FLAG_GENERIC_KERNEL / _ONE_PER_WAVE or 0
     // diagnostics: ICELK_LK_STAMPS=<file> records entry / exit time and placement of every workgroup of the LAST
@@ -107,6 +112,8 @@ struct Ctx {
     size_t proj_cap = 0;
     int seg_vert = 0, seg_upper = 0;   // vertices so far, tracks of the segment (= corners detected)
     bool seg_active = false;
+    bool seg_staged = false;   // the OTHER set holds a new segment waiting for icelk_seg_switch
+    int staged_n = 0;
 
     int last_candidates = 0, last_accepted = 0;   // of the latest detection
     DetectJob job{};
@@ -394,7 +401,7 @@ static void destroy_ctx(Ctx* c)
                     c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.cand, c->D.cand_count,
                     c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.chunk_tot, c->D.cell_cand, c->D.state, c->D.undecided,
                     c->D.acc, c->D.acc_sorted, c->D.acc_count, c->eo[0].raw, c->eo[1].raw, c->eo[0].blk_count, c->eo[1].blk_count,
-                    c->eo[0].max_key, c->eo[1].max_key, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->sb[0].live, c->sb[1].live, c->sb[0].alive, c->sb[1].alive, c->sb[0].order,
+                    c->eo[0].max_key, c->eo[1].max_key, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->sb[0].live, c->sb[1].live, c->sb[0].alive, c->sb[1].alive, c->sb[0].order, c->sb[0].order_border, c->sb[1].order_border,
                     c->sb[1].order, c->sb[0].tracks, c->sb[1].tracks, c->sb[0].quality, c->sb[1].quality, c->d_tracked,
                     c->d_out_tracks, c->d_out_quality, c->d_proj, c->d_keep};
     for (void* p : ptrs)
@@ -679,6 +686,9 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
         B.valid = c->d_valid;
         B.seg_alive = S.alive;
         B.order = c->use_order ? S.order : nullptr;
+        B.order_border = c->use_order ? S.order_border : nullptr;
+        // tiles (half window + search margin) of a feature this close to the edge reach over it at the upper levels
+        c->border_px = c->border_first ? ((std::max(win_w, win_h) / 2 + 6 + 2) << std::max(P.top_level - 1, 0)) : 0;
         // Dealing the sorted sequence to the XCDs pays while neighbouring windows barely overlap (C2: 244 -> 233 us);
         // with dense features every XCD would work on one spot of the frame at a time and its L2 channels
         // serialise (REF: 2 060 us walking the table linearly, 2 680 us dealt, 2 230 us unsorted)
@@ -832,7 +842,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, &c->eo[0].blk_count, candidate_blocks(max_w, max_h) * 4)) ||
         (rc = dmalloc(c, &c->eo[1].blk_count, candidate_blocks(max_w, max_h) * 4)) ||
         (rc = dmalloc(c, &D.key_hist, 1 << 16)) || (rc = dmalloc(c, &D.prune_key, 1)) || (rc = dmalloc(c, (uint8_t**)&D.sort_tmp, D.sort_tmp_bytes)) ||
-        (rc = dmalloc(c, &c->sb[0].live, 2 * np)) || (rc = dmalloc(c, &c->sb[0].alive, np)) || (rc = dmalloc(c, &c->sb[0].order, np)) ||
+        (rc = dmalloc(c, &c->sb[0].live, 2 * np)) || (rc = dmalloc(c, &c->sb[0].alive, np)) || (rc = dmalloc(c, &c->sb[0].order, np)) || (rc = dmalloc(c, &c->sb[0].order_border, 1)) || (rc = dmalloc(c, &c->sb[1].order_border, 1)) ||
         (rc = dmalloc(c, &c->sb[1].live, 2 * np)) || (rc = dmalloc(c, &c->sb[1].alive, np)) || (rc = dmalloc(c, &c->sb[1].order, np)) ||
         (rc = dmalloc(c, &c->sb[0].tracks, np * kMaxVert * 2)) || (rc = dmalloc(c, &c->sb[1].tracks, np * kMaxVert * 2)) ||
         (rc = dmalloc(c, &c->sb[0].quality, np * (kMaxVert - 1))) || (rc = dmalloc(c, &c->sb[1].quality, np * (kMaxVert - 1))) ||
@@ -840,6 +850,8 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &c->d_out_quality, np * (kMaxVert - 1))))
         return fail(rc);
     c->use_order = getenv("ICELK_NO_ORDER") == nullptr;
+    c->border_first = getenv("ICELK_NO_BORDER_FIRST") == nullptr;
+    if (!c->border_first) c->border_px = 0;
     if ((rc = dmalloc(c, &c->d_iters, (size_t)max_pts))) return fail(rc);
     if (const char* sp = getenv("ICELK_LK_STAMPS")) {
         c->stamps_path = sp;
@@ -1398,11 +1410,11 @@ int icelk_seg_detect_prepare(icelk_t* h, int slot, int use_mask, int block_size)
     return detect_prepare(c, slot, use_mask, block_size);
 }
 
-int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n)
+// The corners of the detection in flight become a new segment in the OTHER set of segment buffers (the current one
+// keeps being tracked); icelk_seg_switch makes it current.
+static int seg_stage(Ctx* c, int max_corners, int* out_n)
 {
-    if (!h) return ICELK_EARG;
-    Ctx* c = C(h);
-    HIPCHK(c, hipSetDevice(c->device));
+    if (c->seg_staged) FAIL(c, ICELK_ESTATE, "a staged segment is waiting for icelk_seg_switch");
     int n = 0;
     int rc = detect_finish(c, max_corners, c->max_pts, &n);
     if (rc) return rc;
@@ -1412,18 +1424,51 @@ int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n)
     const hipStream_t ds = c->det_stream;
     HIPCHK(c, hipStreamWaitEvent(ds, nb.used, 0));
     launch_seg_init(ds, c->d_corners, n, nb.live, nb.alive, nb.tracks, kMaxVert);
-    if (c->use_order) launch_seg_order(ds, c->d_corners, n, c->job.w, c->job.h, nb.order);
+    if (c->use_order) launch_seg_order(ds, c->d_corners, n, c->job.w, c->job.h, c->border_px, nb.order, nb.order_border);
     rc = check_launch(c, "seg_init");
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->corners_free, ds));
     HIPCHK(c, hipEventRecord(c->seg_ready, ds));
+    c->seg_staged = true;
+    c->staged_n = n;
+    if (out_n) *out_n = n;
+    return ICELK_OK;
+}
+
+static int seg_switch(Ctx* c)
+{
+    if (!c->seg_staged) FAIL(c, ICELK_ESTATE, "no staged segment (icelk_seg_detect_stage has not been called)");
+    c->seg_staged = false;
     c->sb_cur ^= 1;
     c->seg_ready_pending = true;
     c->seg_vert = 1;
-    c->seg_upper = n;
+    c->seg_upper = c->staged_n;
     c->seg_active = true;
-    if (out_n) *out_n = n;
     return ICELK_OK;
+}
+
+int icelk_seg_detect_stage(icelk_t* h, int max_corners, int* out_n)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    return seg_stage(c, max_corners, out_n);
+}
+
+int icelk_seg_switch(icelk_t* h)
+{
+    if (!h) return ICELK_EARG;
+    return seg_switch(C(h));
+}
+
+int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = seg_stage(c, max_corners, out_n);
+    if (rc) return rc;
+    return seg_switch(c);
 }
 
 int icelk_seg_detect(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level, double min_distance,

@@ -93,6 +93,7 @@ struct LKBuffers {
     const int* n_dev;    // optional device-side count (overrides n when non-null)
     const int* order;    // optional launch order (k_tracks.hip k_seg_order); results do not depend on it
     int order_plain;     // walk the order table linearly instead of dealing it to the XCDs (dense features)
+    const int* order_border;   // number of leading table entries that are border features: launched first, undealt
     // Segment mode (icelk_seg_track): the launch itself keeps the track table.  Feature f is track f of the
     // segment; dead tracks (seg_alive[f] == 0) exit at once, survivors of the forward-backward test get their
     // new vertex and distance appended and their position updated in place -- the Python loop of
@@ -185,7 +186,7 @@ size_t sort_keys_asc(hipStream_t s, void* tmp, size_t tmp_bytes, const unsigned 
                      int n, int end_bit);
 void launch_polygon_mask(hipStream_t s, const double* poly, int n, double crop_left, double crop_top, int w, int h,
                          uint8_t* mask, int pitch);
-void launch_seg_order(hipStream_t s, const float* xy, int n, int w, int h, int* order);
+void launch_seg_order(hipStream_t s, const float* xy, int n, int w, int h, int border_px, int* order, int* border_count);
 void launch_seg_stats(hipStream_t s, const uint8_t* alive, int n, const unsigned long long* tracked_shards,
                       unsigned long long* host_out);
 // rows of the alive tracks, in track order, packed into out_tracks (n_alive, nvert, 2) / out_quality

@@ -319,8 +319,8 @@ template <int PPL>
 void launch_ppl(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
                 bool fb, size_t lds)
 {
-    if (fb) hipLaunchKernelGGL((k_lk<PPL, true>), dim3(B.order ? (n + 7) & ~7 : n), dim3(64), lds, s, I, J, B, n, P);
-    else hipLaunchKernelGGL((k_lk<PPL, false>), dim3(B.order ? (n + 7) & ~7 : n), dim3(64), lds, s, I, J, B, n, P);
+    if (fb) hipLaunchKernelGGL((k_lk<PPL, true>), dim3(B.order ? (n + 15) & ~7 : n), dim3(64), lds, s, I, J, B, n, P);
+    else hipLaunchKernelGGL((k_lk<PPL, false>), dim3(B.order ? (n + 15) & ~7 : n), dim3(64), lds, s, I, J, B, n, P);
 }
 
 }  // namespace

@@ -263,8 +263,8 @@ template <int WW, int WH>
 void launch_fast(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
                  bool fb)
 {
-    if (fb) hipLaunchKernelGGL((k_lk_fast<WW, WH, true>), dim3(B.order ? (n + 7) & ~7 : n), dim3(64), 0, s, I, J, B, n, P);
-    else hipLaunchKernelGGL((k_lk_fast<WW, WH, false>), dim3(B.order ? (n + 7) & ~7 : n), dim3(64), 0, s, I, J, B, n, P);
+    if (fb) hipLaunchKernelGGL((k_lk_fast<WW, WH, true>), dim3(B.order ? (n + 15) & ~7 : n), dim3(64), 0, s, I, J, B, n, P);
+    else hipLaunchKernelGGL((k_lk_fast<WW, WH, false>), dim3(B.order ? (n + 15) & ~7 : n), dim3(64), 0, s, I, J, B, n, P);
 }
 
 }  // namespace

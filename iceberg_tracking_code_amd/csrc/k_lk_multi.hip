@@ -382,9 +382,17 @@ __device__ __forceinline__ int feature_slot(const LKBuffers& B, int b, int f, in
         if (i >= count) return -1;
         return B.order ? B.order[i] : i;
     }
-    const int chunk = (count + 7) >> 3, j = (b >> 3) * F + f;
-    const int idx = (b & 7) * chunk + j;
-    return (j < chunk && idx < count) ? B.order[idx] : -1;
+    // border features first (F per workgroup), the rest dealt to the XCDs in contiguous eighths
+    const int nb = B.order_border ? *B.order_border : 0;
+    const int nbw = (nb + F - 1) / F;   // workgroups that carry border features
+    if (b < nbw) {
+        const int i = b * F + f;
+        return i < nb ? B.order[i] : -1;
+    }
+    const int rest = count - nb, bb = b - nbw;
+    const int chunk = (rest + 7) >> 3, j = (bb >> 3) * F + f;
+    const int idx = (bb & 7) * chunk + j;
+    return (j < chunk && idx < rest) ? B.order[nb + idx] : -1;
 }
 
 template <int WW, int WH, int F>
@@ -448,8 +456,8 @@ void launch_multi(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuf
 {
     int grid;
     if (B.order && !B.order_plain) {
-        const int chunk = (n + 7) >> 3;
-        grid = 8 * ((chunk + F - 1) / F);
+        // ceil(nb / F) border workgroups + 8 * ceil(ceil((n - nb) / 8) / F) dealt ones <= n / F + 17 for any nb
+        grid = n / F + 18;
     } else {
         grid = (n + F - 1) / F;
     }

@@ -24,33 +24,42 @@ __global__ void k_seg_init(const float* __restrict__ corners, int n, float* __re
     tracks[((size_t)i * max_vert) * 2 + 1] = y;
 }
 
-// Launch order of a segment's tracks.  Results do not depend on it, HBM traffic does: the detector hands the
-// corners over in response order, i.e. scattered over the frame, so consecutive workgroups of the tracker touch
-// unrelated cache lines (measured: 5x the algorithmic bytes).  One counting sort per segment bins the tracks
-// into cells of cw x ch px, cells in raster order; the tracker then deals that sequence to the 8 XCDs in
-// contiguous eighths (lk_common.h launch_slot), so each XCD's L2 sees one compact part of the frame.
+// Launch order of a segment's tracks.  Results do not depend on it, time does, twice over:
+//  * HBM traffic: the detector hands the corners over in response order, i.e. scattered over the frame, so consecutive
+//    workgroups of the tracker touch unrelated cache lines (measured: 5x the algorithmic bytes).  One counting sort per
+//    segment bins the tracks into cells of cw x ch px, cells in raster order; the tracker then deals that sequence to the
+//    8 XCDs in contiguous eighths (lk_common.h launch_slot), so each XCD's L2 sees one compact part of the frame.
+//  * the tail of the launch: a feature whose tiles reach over the frame border is staged through the reflecting loader
+//    and masks its template: it takes 1.2-1.6x as long as an interior feature (74 us against 48 us at 4000x3000, 21x21).
+//    Launched wherever the sort puts them, some start last and the launch waits for them alone.  They form bin 0 here:
+//    the table starts with them, the tracker starts them first (longest-processing-time-first); their number is left in
+//    border_count for launch_slot.
 constexpr int kOrderBins = 8192;
 __global__ __launch_bounds__(1024) void k_seg_order(const float* __restrict__ xy, int n, int cw_shift, int ch_shift,
-                                                    int cells_x, int ncells, int* __restrict__ order)
+                                                    int cells_x, int ncells, int w, int h, int border_px,
+                                                    int* __restrict__ order, int* __restrict__ border_count)
 {
-    __shared__ int bins[kOrderBins];
+    __shared__ int bins[kOrderBins + 1];
     __shared__ int wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < ncells; i += 1024) bins[i] = 0;
+    const int nb = ncells + 1;
+    for (int i = tid; i < nb; i += 1024) bins[i] = 0;
     __syncthreads();
     auto cell_of = [&](int i) {
         const int x = (int)xy[2 * i], y = (int)xy[2 * i + 1];
+        if (x < border_px || y < border_px || x >= w - border_px || y >= h - border_px) return 0;
         int c = (y >> ch_shift) * cells_x + (x >> cw_shift);
-        return c < 0 ? 0 : (c >= ncells ? ncells - 1 : c);
+        return 1 + (c < 0 ? 0 : (c >= ncells ? ncells - 1 : c));
     };
     for (int i = tid; i < n; i += 1024) atomicAdd(&bins[cell_of(i)], 1);
     __syncthreads();
-    // exclusive scan of the bins: 8 consecutive bins per thread, wave prefix by shuffles, 16 wave totals
-    int v[8], tsum = 0;
+    if (tid == 0) *border_count = bins[0];
+    // exclusive scan of the bins: 9 consecutive bins per thread, wave prefix by shuffles, 16 wave totals
+    int v[9], tsum = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int b = tid * 8 + k;
-        v[k] = b < ncells ? bins[b] : 0;
+    for (int k = 0; k < 9; k++) {
+        const int b = tid * 9 + k;
+        v[k] = b < nb ? bins[b] : 0;
         tsum += v[k];
     }
     int incl = tsum;
@@ -64,9 +73,9 @@ __global__ __launch_bounds__(1024) void k_seg_order(const float* __restrict__ xy
     int base = incl - tsum;
     for (int k = 0; k < wave; k++) base += wave_tot[k];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int b = tid * 8 + k;
-        if (b < ncells) bins[b] = base;
+    for (int k = 0; k < 9; k++) {
+        const int b = tid * 9 + k;
+        if (b < nb) bins[b] = base;
         base += v[k];
     }
     __syncthreads();
@@ -158,7 +167,7 @@ void launch_seg_init(hipStream_t s, const float* corners, int n, float* xy, uint
     hipLaunchKernelGGL(k_seg_init, dim3((n + 255) / 256), dim3(256), 0, s, corners, n, xy, alive, tracks, max_vert);
 }
 
-void launch_seg_order(hipStream_t s, const float* xy, int n, int w, int h, int* order)
+void launch_seg_order(hipStream_t s, const float* xy, int n, int w, int h, int border_px, int* order, int* border_count)
 {
     if (n <= 0) return;
     int cw = 5, ch = 6;   // 32 x 64 px cells; coarsen until they fit the LDS histogram
@@ -172,7 +181,7 @@ void launch_seg_order(hipStream_t s, const float* xy, int n, int w, int h, int* 
         else ch++;
     }
     const int nc = cells(cx);
-    hipLaunchKernelGGL(k_seg_order, dim3(1), dim3(1024), 0, s, xy, n, cw, ch, cx, nc, order);
+    hipLaunchKernelGGL(k_seg_order, dim3(1), dim3(1024), 0, s, xy, n, cw, ch, cx, nc, w, h, border_px, order, border_count);
 }
 
 void launch_seg_stats(hipStream_t s, const uint8_t* alive, int n, const unsigned long long* tracked_shards,

@@ -92,14 +92,18 @@ __device__ __forceinline__ long long wave_sum_exact(int v)
 // spatially sorted sequence of features and workgroup b takes entry (b % 8) * ceil(count / 8) + b / 8:
 // workgroups are dispatched round-robin over the 8 XCDs, so each XCD (own L2) walks one contiguous eighth of
 // the sequence.  With order_plain the table is walked linearly (consecutive workgroups = neighbouring features on
-// DIFFERENT XCDs).  -1 = nothing to do; the grid must hold 8 * ceil(count / 8) workgroups.
+// DIFFERENT XCDs).  -1 = nothing to do; the grid must hold count + 8 workgroups (rounded up to 8).
 __device__ __forceinline__ int launch_slot(const LKBuffers& B, int b, int count)
 {
     if (!B.order) return b < count ? b : -1;
     if (B.order_plain) return b < count ? B.order[b] : -1;
-    const int chunk = (count + 7) >> 3, j = b >> 3;
-    const int idx = (b & 7) * chunk + j;
-    return (j < chunk && idx < count) ? B.order[idx] : -1;
+    // the table starts with the border features (slow: launched first, on whatever XCD), the rest is dealt
+    const int nb = B.order_border ? *B.order_border : 0;
+    if (b < nb) return B.order[b];
+    const int rest = count - nb, bb = b - nb;
+    const int chunk = (rest + 7) >> 3, j = bb >> 3;
+    const int idx = (bb & 7) * chunk + j;
+    return (j < chunk && idx < rest) ? B.order[nb + idx] : -1;
 }
 
 // segment-mode epilogue of a fused forward+backward launch (one lane per feature calls it)

@@ -178,7 +178,10 @@ class SegmentTracker:
         self.lookahead = bool(lookahead)
         self._pyr_ahead = None    # slot whose pyramid was enqueued ahead of its step
         self._resident = False    # inside push_slot
-        self._det_started = False  # the detection of the coming detection frame is already in flight
+        self._det_for = None      # frame counter whose detection (min-distance stage) is in flight
+        self._prepared_for = None  # frame counter whose corner candidates have been prepared ahead
+        self._staged = False      # a new segment waits in the spare set for the switch
+        self._staged_n = 0
 
     # -- frame sources --------------------------------------------------------------------------
     def _next_slot(self):
@@ -223,16 +226,16 @@ class SegmentTracker:
             raise RuntimeError("no prefetched frame")
         s = self._prefetched.pop(0)
         q = self._prefetched
-        return self._step(s, wait, q[0] if q else None, q[1] if len(q) > 1 else None)
+        return self._step(s, wait, q[0] if q else None, q[1] if len(q) > 1 else None, q[2] if len(q) > 2 else None)
 
-    def push_slot(self, slot, wait=True, next_slot=None, next2_slot=None):
+    def push_slot(self, slot, wait=True, next_slot=None, next2_slot=None, next3_slot=None):
         """Use a frame that already sits in `slot` (level 0 resident in HBM); its pyramid is rebuilt.
-        `next_slot`, `next2_slot`: where the following two frames already sit, if they do (see `_step`)."""
+        `next_slot`, `next2_slot`, `next3_slot`: where the following frames already sit, if they do (see `_step`)."""
         if self._pyr_ahead != slot:
             self.ctx.drop_pyramid(slot)
         self._resident = True
         try:
-            return self._step(slot, wait, next_slot, next2_slot)
+            return self._step(slot, wait, next_slot, next2_slot, next3_slot)
         finally:
             self._resident = False
 
@@ -246,26 +249,35 @@ class SegmentTracker:
         self.ctx.seg_detect_begin(slot, self.fp["maxCorners"], self.fp["qualityLevel"], self.fp["minDistance"],
                                   self.use_mask, self.fp.get("blockSize", 3))
 
-    def _step(self, slot, wait, next_slot=None, next2_slot=None):
-        """One pass of the loop body.  `next_slot` / `next2_slot`: slots of the two FOLLOWING frames when they are
-        already on their way to the device (prefetched uploads, resident ring).  The detector needs nothing but
-        its own frame, so work for a coming detection frame is started early and runs beside the tracker
-        launches of the steps in between: its corner candidates two steps ahead (`seg_detect_prepare`, spare
-        buffer, third stream), its min-distance stage one step ahead.  Results are those of the serial order."""
+    def _step(self, slot, wait, next_slot=None, next2_slot=None, next3_slot=None):
+        """One pass of the loop body.  `next_slot` / `next2_slot` / `next3_slot`: slots of the FOLLOWING frames when they
+        are already on their way to the device (prefetched uploads, resident ring).  The detector needs nothing but its
+        own frame, so the work for a coming detection frame c is spread over the steps before it and runs beside their
+        tracker launches: corner candidates at step c-3 (`seg_detect_prepare`, spare buffer, own stream), min-distance
+        stage at c-2 (`seg_detect_begin`), and at c-1 the one host round trip of a detection, the sort and the new
+        segment's initialisation in the spare set of segment buffers (`seg_detect_stage`).  At step c only the switch is
+        left (no GPU work, no wait), so the tracker launch of frame c+1 never waits for the host.  With less lookahead
+        the same calls move later (candidates c-2, min-distance c-1, stage + switch at c); with none, everything
+        happens at c.  Results are those of the serial order either way."""
         out = None
         prev = self.cur
         T = self.track_len
-        detect = self.counter % T == 0
+        c = self.counter
+        detect = c % T == 0
         ahead = self.lookahead and T >= 2
-        if ahead and next2_slot is not None and (self.counter + 2) % T == 0:
-            self.ctx.seg_detect_prepare(next2_slot, self.use_mask, self.fp.get("blockSize", 3))
-        if detect and not self._det_started:
-            # start it first, on its own stream, so that it runs beside the tracker launch below (the reference
-            # does them back to back, s1:323-326 then s1:437)
+        bs = self.fp.get("blockSize", 3)
+        # corner candidates of a coming detection frame, as early as its slot is known (three steps ahead at most)
+        if ahead:
+            for k, s_k in ((3, next3_slot), (2, next2_slot)):
+                if s_k is not None and (c + k) % T == 0 and self._prepared_for != c + k:
+                    self.ctx.seg_detect_prepare(s_k, self.use_mask, bs)
+                    self._prepared_for = c + k
+                    break
+        if detect and self._det_for != c and not self._staged:
+            # nothing was started ahead for this detection frame: start it now, on its own stream, so that it runs
+            # beside the tracker launch below (the reference does them back to back, s1:323-326 then s1:437)
             self._detect_begin(slot)
-        elif ahead and not detect and next_slot is not None and (self.counter + 1) % T == 0:
-            self._detect_begin(next_slot)
-            self._det_started = True
+            self._det_for = c
         if self.active:
             self.ctx.seg_track(prev, slot, self.lk["winSize"], self.lk["maxLevel"], self.lk["criteria"],
                                self.lk.get("minEigThreshold", 1e-4), self.fb_threshold, wait=False)
@@ -276,14 +288,33 @@ class SegmentTracker:
                 self.ctx.drop_pyramid(next_slot)   # a resident ring is rebuilt on every visit
             self.ctx.build_pyramid_ahead(next_slot, self.lk["winSize"], self.lk["maxLevel"])
             self._pyr_ahead = next_slot
+        if not detect and self._det_for == c + 1:
+            # the detection of the NEXT frame is in flight: take its host round trip now and build the new segment in
+            # the spare set, beside the segment that is still being tracked
+            self._staged_n = self.ctx.seg_detect_stage(self.fp["maxCorners"])
+            self._staged = True
+            self._det_for = None
         if detect:
-            if self.counter > 0 and wait:
+            if c > 0 and wait:
                 tracks, quality = self.ctx.seg_read()
                 out = (self.seg_first, tracks, quality)
-            self.n_detected = self.ctx.seg_detect_finish(self.fp["maxCorners"])
-            self._det_started = False
+            if self._staged:
+                self.ctx.seg_switch()
+                self.n_detected = self._staged_n
+                self._staged = False
+            else:
+                self.n_detected = self.ctx.seg_detect_finish(self.fp["maxCorners"])
+                self._det_for = None
             self.active = True
-            self.seg_first = self.counter
+            self.seg_first = c
+        # min-distance stage of a coming detection frame: two steps ahead when its slot is known, else one step ahead
+        # (behind the tracker launch of this step in issue order: the launch on the critical path goes out first)
+        if ahead and self._det_for is None and not self._staged:
+            for k, s_k in ((2, next2_slot), (1, next_slot)):
+                if s_k is not None and (c + k) % T == 0:
+                    self._detect_begin(s_k)
+                    self._det_for = c + k
+                    break
         self.cur = slot
         self.counter += 1
         return out

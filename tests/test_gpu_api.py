@@ -148,6 +148,39 @@ def test_prefetched_uploads_equal_blocking_upload(synth, track_len):
         assert ta.shape[1] == track_len + 1
 
 
+@pytest.mark.parametrize("track_len", [2, 3, 4])
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_resident_ring_with_lookahead_equals_serial_loop(synth, track_len, depth):
+    """Frames resident in HBM (bench.py's source): with the next 1, 2 or 3 slots known, the work of a coming detection
+    frame moves ahead of it (candidates c-3, min-distance c-2, the host round trip + the new segment's initialisation in
+    the spare segment set at c-1, only the switch at c).  The segments -- read out at every detection frame -- must be
+    those of the loop that does everything at frame c."""
+    from iceberg_tracking_code_amd import Context, SegmentTracker
+    w, h, n = 640, 360, 14
+    frames, _ = synth.sequence(w, h, n, seed=33, max_step_px=2.0)
+    fp = dict(maxCorners=300, qualityLevel=0.007, minDistance=10, blockSize=10)
+    lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
+    ref = SegmentTracker(w, h, track_len, fp, lk, max_pts=4096, lookahead=False)
+    want = [s for s in (ref.push(f) for f in frames) if s is not None]
+    ref.close()
+    ctx = Context(w, h, n_slots=n, max_pts=4096)
+    for i, f in enumerate(frames):
+        ctx.upload_gray(i, f)
+    trk = SegmentTracker(w, h, track_len, fp, lk, ctx=ctx)
+    got = []
+    for i in range(n):
+        nxt = [i + k if (i + k < n and k <= depth) else None for k in (1, 2, 3)]
+        s = trk.push_slot(i, wait=True, next_slot=nxt[0], next2_slot=nxt[1], next3_slot=nxt[2])
+        if s is not None:
+            got.append(s)
+    n_live, _ = trk.live()
+    trk.close()
+    assert len(got) == len(want) == (n - 1) // track_len and n_live > 0
+    for (fa, ta, qa), (fb, tb, qb) in zip(want, got):
+        assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb) and len(ta) > 150
+        assert ta.shape[1] == track_len + 1
+
+
 def test_launch_order_is_invisible(synth, monkeypatch):
     """The spatial launch order of a segment's tracks (k_seg_order + XCD dealing) changes which workgroup tracks
     which feature, never a result: ICELK_NO_ORDER=1 must give identical segments."""

@@ -20,7 +20,7 @@ fp = dict(maxCorners=10000, qualityLevel=0.007, minDistance=10, blockSize=10)
 lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
 trk = SegmentTracker(w, h, 2, feature_params=fp, lk_params=lk, ctx=ctx)
 o, i, d = [], 0, 1
-for _ in range(K + 3):
+for _ in range(K + 4):
     o.append(i)
     if i + d < 0 or i + d >= ring:
         d = -d
@@ -29,7 +29,7 @@ t = np.zeros(K)
 t0 = time.perf_counter()
 for k in range(K):
     a = time.perf_counter()
-    trk.push_slot(o[k], wait=False, next_slot=o[k + 1], next2_slot=o[k + 2])
+    trk.push_slot(o[k], wait=False, next_slot=o[k + 1], next2_slot=o[k + 2], next3_slot=o[k + 3])
     t[k] = time.perf_counter() - a
 ctx.sync()
 el = time.perf_counter() - t0
