@@ -1,25 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- frame-pairs/s and tracked-features/s of the sparse LK tracking loop on MI355X.
 
-    python bench.py --gpus 1 --steps 200 --warmup 10
+    python bench.py --gpus 1 --steps 200 --warmup 10               # BASELINE.json configs[1] (C2), the headline
+    python bench.py --config c3                                    # configs[2]: 64 pairs streamed from pinned host memory
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # configs[3] (C4) shape: sharded sequence + RCCL gather
 
-A "step" is one pass of the reference's frame loop body (s1_lucaskanade_tracking.py:307-450) over one new
-4000x3000 frame that is already resident in HBM: Gaussian pyramid of the new frame, fused forward +
-backward pyramidal LK of all live features against the previous frame, forward-backward filter and
-track-table append, and -- every `track_len` (= 2, s1:128) frames -- Shi-Tomasi detection of up to 10 000
-new features (the reference's detector parameters s1:240-243 with maxCorners capped at 10 000 as
-BASELINE.json configs[1] asks).  Nothing is skipped or cached inside the timed region; no host transfer
-of images is in it either (the PCIe-inclusive rate is in DESIGN.md).
+A "step" is one pass of the reference's frame loop body (s1_lucaskanade_tracking.py:307-450) over one new frame that is
+already resident in HBM: Gaussian pyramid of the new frame, fused forward + backward pyramidal LK of all live features
+against the previous frame, forward-backward filter and track-table append, and -- every `track_len` (= 2, s1:128)
+frames -- Shi-Tomasi detection of new features (the reference's detector parameters s1:240-243; maxCorners capped at
+10 000 as BASELINE.json configs[1] asks).  Nothing is skipped or cached inside the timed region; no host transfer of
+images is in it either (`--config c3` reports the PCIe-inclusive rate beside it, never as `value`).
 
-Multi-GPU: every rank runs its own shard of independent segments (weak scaling, no data-path collective);
-the only collective is the final RCCL all-gather of the per-rank feature counts (BASELINE.json
-north_star); barriers and the max over ranks of the elapsed time go over gloo.  rank 0 prints ONE JSON line.
+Multi-GPU (world > 1): the ranks shard ONE procedural sequence of world * K + 1 frames by segments
+(sharding.frame_block; a segment = track_len + 1 frames from a detection frame, s1:362,440), no data-path collective
+(weak scaling); after the timed region the per-segment track counts AND the padded track tables (the `tracks` arrays of
+s1:394-395) are all-gathered over RCCL.  Barriers and the max over ranks of the elapsed time go over gloo.  rank 0
+prints ONE JSON line.  An RCCL failure is reported (`count_gather_ok: false`) and makes the run exit non-zero.
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -28,12 +31,18 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+C2_NAME = ("4000x3000 gray, 10k Shi-Tomasi features, winSize 21x21, maxLevel 3 (4 pyramid images), criteria (30, 0.01), "
+           "track_len 2")
 CONFIGS = {
     # BASELINE.json configs[1]: single MI355X, 4000x3000 gray pair, 10k Shi-Tomasi features, 21x21, 3 levels
-    "c2": dict(w=4000, h=3000, max_corners=10000, win=(21, 21), max_level=3, criteria=(3, 30, 0.01),
-               name="C2: 4000x3000 gray, 10k Shi-Tomasi features, winSize 21x21, maxLevel 3 (4 pyramid images), "
-                    "criteria (30, 0.01), track_len 2"),
-    # BASELINE.json configs[4]
+    "c2": dict(w=4000, h=3000, max_corners=10000, win=(21, 21), max_level=3, criteria=(3, 30, 0.01), name="C2: " + C2_NAME),
+    # configs[2]: batch of 64 consecutive 4000x3000 pairs streamed from host (hipMemcpyAsync double buffer)
+    "c3": dict(w=4000, h=3000, max_corners=10000, win=(21, 21), max_level=3, criteria=(3, 30, 0.01),
+               name="C3: 65 consecutive frames (64 pairs) of " + C2_NAME),
+    # configs[3]: sequence sharded by segments over the ranks, RCCL gather of the track tables
+    "c4": dict(w=4000, h=3000, max_corners=10000, win=(21, 21), max_level=3, criteria=(3, 30, 0.01),
+               name="C4 (scaled to world x steps + 1 frames): procedural sequence of " + C2_NAME),
+    # configs[4]
     "c5": dict(w=5760, h=3840, max_corners=50000, win=(31, 31), max_level=5, criteria=(3, 30, 0.01),
                name="C5: 5760x3840 gray, 50k features, winSize 31x31, maxLevel 5, track_len 2"),
     # the reference's own literals (s1:240-248) on its typical frame size (create_calibration_file.py:18)
@@ -43,6 +52,7 @@ CONFIGS = {
 DETECT = dict(qualityLevel=0.007, minDistance=10, blockSize=10)   # s1:241-243
 TRACK_LEN = 2                                                       # s1:128
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
 def lk_algorithmic_bytes(w, h, win, top_level, n):
@@ -84,57 +94,157 @@ def ping_pong(n_ring, count):
     return out
 
 
-def cpu_baseline(cfg, seconds_budget=25.0):
-    """The CPU oracle (oracle/, kind "port") timed on this host over the same loop body: per pair one
-    forward+backward LK of the live features (two pyramid builds + Scharr each, as OpenCV does) and every
-    TRACK_LEN-th pair a detection.  Bounded sample; all host cores via OpenMP."""
+def motion_tables(n, seed, motion):
+    """(shifts, affines) of frames 0..n-1: a seeded random walk of sub-pixel shifts of up to 3 px per frame, and -- for
+    motion == "shear" -- of affine coefficients within +-0.5 %, so that the displacement differs across
+    the frame and the coarse pyramid levels have work to do."""
+    from iceberg_tracking_code_amd import synth
+    sh = synth.shifts(n, seed=seed)
+    af = synth.affines(n, seed=seed) if motion == "shear" else np.zeros((n, 4), np.int64)
+    return sh, af
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def usable_cores():
+    """Cores this process may really use: the affinity mask, cut by the cgroup CPU quota (a GPU box hands a container a
+    share of the host: os.cpu_count() still reports the whole machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def probe_cv2():
+    """probe, don't assume."""
+    try:
+        import cv2
+        return dict(present=True, version=cv2.__version__, threads=int(cv2.getNumThreads()))
+    except Exception as exc:   # ImportError here and on the GPU box
+        return dict(present=False, error="%s: %s" % (type(exc).__name__, exc))
+
+
+def _oracle_unit(oracle, frames, maxc, cfg):
+    """One detection + TRACK_LEN forward/backward pairs of the reference loop body on the CPU oracle."""
+    pts = oracle.good_features(frames[0], maxc, DETECT["qualityLevel"], DETECT["minDistance"], None, DETECT["blockSize"])
+    live = pts.reshape(-1, 2) if pts is not None else np.zeros((0, 2), np.float32)
+    feats = 0
+    for k in range(TRACK_LEN):
+        r = oracle.track_fb(frames[k], frames[k + 1], live, cfg["win"], cfg["max_level"], cfg["criteria"])
+        feats += len(live)
+        live = r["p1"][r["valid"].astype(bool)]
+    return feats
+
+
+def _cv2_unit(cv2, frames, maxc, cfg):
+    """The reference's own call sequence (s1:323,326,329-333,437) on cv2, same frames."""
+    fp = dict(maxCorners=maxc if maxc > 0 else 50000000, qualityLevel=DETECT["qualityLevel"],
+              minDistance=DETECT["minDistance"], blockSize=DETECT["blockSize"])
+    lk = dict(winSize=cfg["win"], maxLevel=cfg["max_level"], criteria=cfg["criteria"])
+    p = cv2.goodFeaturesToTrack(frames[0], mask=None, **fp)
+    feats = 0
+    for k in range(TRACK_LEN):
+        if p is None or len(p) == 0:
+            break
+        p1, _, _ = cv2.calcOpticalFlowPyrLK(frames[k], frames[k + 1], p, None, **lk)
+        p0r, _, _ = cv2.calcOpticalFlowPyrLK(frames[k + 1], frames[k], p1, None, **lk)
+        d = abs(p - p0r).reshape(-1, 2)
+        feats += len(p)
+        p = p1[np.hypot(d[:, 0], d[:, 1]) < 1]
+    return feats
+
+
+def cpu_baseline(cfg, motion):
+    """the loop body timed on THIS host's cores in the same run -- 1 warm-up + median of 5, at all
+    cores and at 1 thread, on a bounded sample (a full-width band of the frame, features scaled alike), the repo's own C
+    restatement (oracle/, kind "port") always and the reference's cv2 call sequence too where cv2 imports."""
     import oracle
     from iceberg_tracking_code_amd import synth
     oracle.build()
-    cores = oracle.set_threads(0)
     w, h = cfg["w"], cfg["h"]
-    # a horizontal band of the full frame keeps the sample bounded while every stage sees full-width rows
-    band_h = min(h, 750)
-    sh = synth.shifts(3, seed=1234)
-    frames = [synth.frame(w, band_h, int(sx), int(sy), 1234) for sx, sy in sh]
-    maxc = max(1, int(round(cfg["max_corners"] * band_h / h))) if cfg["max_corners"] > 0 else 0
-    t0 = time.perf_counter()
-    pairs, feats = 0, 0
-    while True:
-        pts = oracle.good_features(frames[0], maxc, DETECT["qualityLevel"], DETECT["minDistance"], None,
-                                   DETECT["blockSize"])
-        live = pts.reshape(-1, 2) if pts is not None else np.zeros((0, 2), np.float32)
-        for k in range(TRACK_LEN):
-            r = oracle.track_fb(frames[k], frames[k + 1], live, cfg["win"], cfg["max_level"], cfg["criteria"])
-            feats += len(live)
-            live = r["p1"][r["valid"].astype(bool)]
-            pairs += 1
-        if time.perf_counter() - t0 > seconds_budget * 0.5 or pairs >= 8:
-            break
-    dt = time.perf_counter() - t0
-    scale = band_h / float(h)   # a band is band_h/h of a frame pair
-    return dict(value=pairs * scale / dt, unit="frame-pairs/s", cores=cores, kind="port",
-                tracked_features_per_sec=feats / dt,
-                sample="%d pairs of a %dx%d band (%.0f%% of the %dx%d frame, features scaled alike) through "
-                       "oracle/icelk_oracle.c: detect every %d pairs + forward/backward LK, OpenMP over %d threads"
-                       % (pairs, w, band_h, 100 * scale, w, h, TRACK_LEN, cores))
+    sh, af = motion_tables(TRACK_LEN + 1, 1234, motion)
+
+    def band(rows):
+        fr = [synth.frame(w, rows, int(sh[i, 0]), int(sh[i, 1]), 1234, affine=af[i]) for i in range(TRACK_LEN + 1)]
+        mc = max(1, int(round(cfg["max_corners"] * rows / h))) if cfg["max_corners"] > 0 else 0
+        return fr, mc
+
+    def timed(fn, frames, mc, reps):
+        fn(frames, mc)   # warm-up
+        ts, feats = [], 0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            feats = fn(frames, mc)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), feats
+
+    out = dict(unit="frame-pairs/s", kind="port", cpu_model=cpu_model(), os_cpu_count=os.cpu_count(),
+               usable_cores=usable_cores(), cv2=probe_cv2(),
+               protocol="1 warm-up + median of 5 repeats of [1 detection + %d forward/backward pairs]" % TRACK_LEN)
+    all_cores = oracle.set_threads(usable_cores())
+    rows_all = min(h, 750)
+    fr, mc = band(rows_all)
+    t_all, feats = timed(lambda f, m: _oracle_unit(oracle, f, m, cfg), fr, mc, 5)
+    scale = rows_all / float(h)
+    out.update(value=TRACK_LEN * scale / t_all, cores=all_cores, tracked_features_per_sec=feats / t_all,
+               sample="a %dx%d band (%.0f%% of the %dx%d frame, %d features) through oracle/icelk_oracle.c, OpenMP over %d "
+                      "threads" % (w, rows_all, 100 * scale, w, h, mc, all_cores))
+    rows_1 = min(h, 250)
+    fr1, mc1 = band(rows_1)
+    oracle.set_threads(1)
+    t_1, feats1 = timed(lambda f, m: _oracle_unit(oracle, f, m, cfg), fr1, mc1, 5)
+    oracle.set_threads(all_cores)
+    out["one_thread"] = dict(value=TRACK_LEN * (rows_1 / float(h)) / t_1, cores=1, tracked_features_per_sec=feats1 / t_1,
+                             sample="a %dx%d band (%.1f%% of the frame, %d features)" % (w, rows_1, 100.0 * rows_1 / h, mc1))
+    if out["cv2"]["present"]:   # never silently substituted: reported beside the port, kind "reference"
+        import cv2
+        res = {}
+        for nthr, (frs, mcs, rows) in ((all_cores, (fr, mc, rows_all)), (1, (fr1, mc1, rows_1))):
+            cv2.setNumThreads(nthr)
+            t, fe = timed(lambda f, m: _cv2_unit(cv2, f, m, cfg), frs, mcs, 5)
+            res["threads_%d" % nthr] = dict(value=TRACK_LEN * (rows / float(h)) / t, tracked_features_per_sec=fe / t)
+        out["cv2_reference"] = res
+    else:
+        out["note"] = "OpenCV unavailable on host -- CPU baseline is the repo's own restatement"
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--ring", type=int, default=24, help="distinct frames resident in HBM")
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="default: c2 on one GPU, c4 (sharded sequence + RCCL gather) on several")
+    ap.add_argument("--ring", type=int, default=24, help="distinct frames resident in HBM (c2 / c5 / ref)")
+    ap.add_argument("--motion", default="shear", choices=("shear", "translate"),
+                    help="frame-to-frame motion of the synthetic sequence: sub-pixel translation plus a slowly varying "
+                         "affine deformation of up to 0.5 %% (default), or translation only (the easiest case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="leave out the per-kernel HIP events (and with them the roofline object): shows what they cost")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="start a detection only when its frame is pushed (A/B of the cross-step overlap)")
-    ap.add_argument("--source", default="hbm", choices=("hbm", "host"),
-                    help="hbm: frames resident in HBM (the headline number); host: every frame crosses PCIe from "
-                         "pinned host memory, uploads double-buffered against the tracker (BASELINE.json configs[2])")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: gloo / RCCL print banners to file descriptor 1, so everything but that
@@ -147,12 +257,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch one process per GPU (torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    # Control plane (barriers, max of the elapsed time) over gloo; the RCCL communicator is created only for the one
-    # collective of the path, the final gather of the feature counts, AFTER the timed region: a handle already keeps
-    # four HIP streams busy and a fifth queue on the device costs 25-35 %.
+    # Control plane (barriers, max of the elapsed time) over gloo; the RCCL communicator is created only for the
+    # collectives of the path, the final gathers, AFTER the timed region: a handle already keeps four HIP streams busy
+    # and a fifth queue on the device costs 25-35 %.
     dist = None
     if world > 1 or os.environ.get("ICELK_BENCH_FORCE_DIST"):
         import torch.distributed as dist
@@ -160,35 +272,34 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from iceberg_tracking_code_amd import Context, SegmentTracker
+    from iceberg_tracking_code_amd import Context, SegmentTracker, sharding
 
-    cfg = CONFIGS[args.config]
+    cname = args.config or ("c2" if world == 1 else "c4")
+    cfg = CONFIGS[cname]
     w, h = cfg["w"], cfg["h"]
-    K, W = args.steps, args.warmup
-    ring = max(2, min(args.ring, K + W + 1))
-    host = args.source == "host"
-    if host:
-        ring = min(ring, 8)
+    W = args.warmup
+    K = args.steps if args.steps is not None else (64 if cname == "c3" else 200)
+    if cname == "c3":
+        K = 64   # BASELINE.json configs[2]: 64 consecutive pairs
+    linear = cname in ("c3", "c4")            # a sequence of distinct frames instead of a ping-pong ring
+    ring = (W + K + 1) if linear else max(2, min(args.ring, K + W + 1))
     max_pts = max(cfg["max_corners"], 1 << 14) if cfg["max_corners"] > 0 else 1 << 18
-    ctx = Context(w, h, n_slots=5 if host else ring, max_pts=max_pts, device=local_rank)
-    from iceberg_tracking_code_amd import synth
-    shifts = synth.shifts(ring, seed=1234 + rank)
-    pinned = []
+    seed = 1234
+    # frame g of the GLOBAL sequence (g = 0 is the first timed frame of rank 0; the W warm-up frames precede a rank's
+    # block); ring configs use frames 0..ring-1 of a per-rank sequence
+    if linear:
+        base = rank * K - W
+        sh_all, af_all = motion_tables(world * K + 1 + W, seed, args.motion)
+        sh, af = sh_all[base + W:base + W + ring], af_all[base + W:base + W + ring]
+    else:
+        sh, af = motion_tables(ring, seed + rank, args.motion)
+    ctx = Context(w, h, n_slots=ring, max_pts=max_pts, device=local_rank)
     for i in range(ring):
-        ctx.synth_frame(0 if host else i, w, h, int(shifts[i, 0]), int(shifts[i, 1]), 1234 + rank)
-        if host:   # the same frames, parked in pinned host memory
-            import ctypes
-            img = np.ascontiguousarray(ctx.download_level(0, 0))
-            ptr = ctx.host_alloc(w * h)
-            ctypes.memmove(ptr, img.ctypes.data, w * h)
-            pinned.append(ptr)
+        ctx.synth_frame(i, w, h, int(sh[i, 0]), int(sh[i, 1]), seed if linear else seed + rank, affine=af[i])
     ctx.sync()
 
     fp = dict(maxCorners=cfg["max_corners"], **DETECT)
     lk = dict(winSize=cfg["win"], maxLevel=cfg["max_level"], criteria=cfg["criteria"])
-    tracker = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx,
-                             lookahead=not args.no_lookahead)
-    order = ping_pong(ring, K + W)
 
     def barrier():
         ctx.sync()
@@ -198,79 +309,192 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
 
-    def step(i):
-        if not host:
-            # the following frame is resident too: its detection (if it is a detection frame) may start now
-            tracker.push_slot(order[i], wait=False, next_slot=order[i + 1] if i + 1 < W + K else None,
-                              next2_slot=order[i + 2] if i + 2 < W + K else None,
-                              next3_slot=order[i + 3] if i + 3 < W + K else None)
-            return
-        if i + 2 < W + K:   # frames i+1, i+2 are crossing PCIe while frame i is tracked
-            tracker.prefetch_pinned(pinned[order[i + 2]], w)
-        tracker.push_prefetched(wait=False)
+    def run_resident(tracker, order, first, count):
+        """`count` steps over frames that sit in HBM; the slots of the next three frames are known to the tracker."""
+        n = len(order)
+        for i in range(first, first + count):
+            nxt = [order[i + k] if i + k < n else None for k in (1, 2, 3)]
+            tracker.push_slot(order[i], wait=False, next_slot=nxt[0], next2_slot=nxt[1], next3_slot=nxt[2])
 
-    if host:
-        tracker.prefetch_pinned(pinned[order[0]], w)
-        tracker.prefetch_pinned(pinned[order[1]], w)
-    for i in range(W):
-        step(i)
+    # ---- the timed region -------------------------------------------------------------------------------------------------
+    order = list(range(ring)) if linear else ping_pong(ring, K + W)
+    archive = None
+    if linear:
+        # warm-up on the W frames before the rank's block with a tracker of its own that starts nothing ahead of time:
+        # the timed tracker begins with a clean handle (no detection in flight, no staged segment)
+        warm = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx, lookahead=False)
+        run_resident(warm, order[:W], 0, W)
+        tracker = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx, lookahead=not args.no_lookahead)
+        if cname == "c4":
+            # the rank's finished segments stay on the device: (segments, rows, vertices, 2) float32 + counts, gathered
+            # over RCCL after the timed region (icelk_seg_archive: no host round trip per segment)
+            n_seg = sharding.segment_count(K + 1, TRACK_LEN)
+            rows = max_pts if cfg["max_corners"] <= 0 else cfg["max_corners"]
+            archive = dict(tracks=torch.zeros((max(n_seg, 1), rows, TRACK_LEN + 1, 2), dtype=torch.float32, device="cuda"),
+                           counts=torch.zeros(max(n_seg, 1), dtype=torch.int32, device="cuda"), n=0, rows=rows)
+
+            def on_close(first_frame):
+                s = archive["n"]
+                if s < archive["tracks"].shape[0]:
+                    ctx.seg_archive(archive["tracks"][s].data_ptr(), 0, archive["counts"][s:s + 1].data_ptr(), archive["rows"])
+                    archive["n"] = s + 1
+            tracker.on_close = on_close
+        timed_order = order[W:]
+        t_first, pushes = 0, K + 1    # the first push of a fresh tracker only detects: K + 1 frames = K frame pairs
+    else:
+        tracker = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx, lookahead=not args.no_lookahead)
+        run_resident(tracker, order, 0, W)
+        timed_order = order
+        t_first, pushes = W, K        # steady state: every push tracks one pair
     barrier()
-    _, tracked0 = tracker.live()
+    _, tracked0 = tracker.live() if tracker.active else (0, 0)
+    if linear:
+        tracked0 = ctx.seg_live()[1] if warm.active else 0
     ctx.prof_reset()
     ctx.prof_enable(not args.no_kernel_timing)
     barrier()
     t0 = time.perf_counter()
-    for i in range(W, W + K):
-        step(i)
+    run_resident(tracker, timed_order, t_first, pushes)
     barrier()
     t1 = time.perf_counter()
     ctx.prof_enable(False)
     n_live, tracked1 = tracker.live()
     prof = ctx.prof_table()
+    elapsed = t1 - t0
+    tracked = tracked1 - tracked0
 
-    # the same kernels once more, each ALONE on the device (outside the timed region): inside the pipeline their
-    # HIP-event durations include waiting for wave slots beside the tracker launch
-    alone = {}
-    if rank == 0 and not args.no_kernel_timing and not host:   # the resident ring provides the frames
+    # ---- the same kernels once more, each ALONE on the device (outside the timed region): inside the pipeline their
+    # HIP-event durations include waiting for wave slots beside the tracker launch ------------------------------------------
+    alone, iters, pcie = {}, None, None
+    if rank == 0 and not args.no_kernel_timing:
         bs = DETECT["blockSize"]
+        sl = list(range(min(ring, 6)))
         for _ in range(2):   # first pass warms up
             ctx.sync()
             ctx.prof_reset()
             ctx.prof_enable(True)
             for rep in range(5):      # back to back, one kind at a time
-                s1 = order[(rep + 1) % len(order)]
-                ctx.drop_pyramid(s1)
-                ctx.build_pyramid(s1, cfg["win"], cfg["max_level"])
+                ctx.drop_pyramid(sl[(rep + 1) % len(sl)])
+                ctx.build_pyramid(sl[(rep + 1) % len(sl)], cfg["win"], cfg["max_level"])
             ctx.sync()
             for rep in range(5):
-                ctx.seg_detect_prepare(order[(rep + 1) % len(order)], False, bs)
+                ctx.seg_detect_prepare(sl[(rep + 1) % len(sl)], False, bs)
             ctx.sync()
             for rep in range(5):
-                s0, s1 = order[rep % len(order)], order[(rep + 1) % len(order)]
-                tracker.ctx.seg_track(s0, s1, cfg["win"], cfg["max_level"], cfg["criteria"], 1e-4, 1.0, wait=False)
+                ctx.seg_track(sl[rep % len(sl)], sl[(rep + 1) % len(sl)], cfg["win"], cfg["max_level"], cfg["criteria"], 1e-4,
+                              1.0, wait=False)
             ctx.sync()
             ctx.prof_enable(False)
             alone = ctx.prof_table()
-    elapsed = t1 - t0
-    tracked = tracked1 - tracked0
+        # iterations per feature (SURVEY.md 8d "so this is checkable"): one fresh segment on the bench's own frames
+        ctx.prof_enable(True)
+        nd = ctx.seg_detect(sl[0], cfg["max_corners"], DETECT["qualityLevel"], DETECT["minDistance"], False, bs)
+        ctx.seg_track(sl[0], sl[1], cfg["win"], cfg["max_level"], cfg["criteria"], 1e-4, 1.0)
+        itf, itb = ctx.prof_iterations()
+        ctx.prof_enable(False)
+        if len(itf):
+            top = top_level_of(w, h, cfg["win"], cfg["max_level"])
+            tot = itf + itb
+            iters = dict(features=int(nd), levels=top + 1, mean_per_level_forward=float(itf.mean()) / (top + 1),
+                         mean_per_level_backward=float(itb.mean()) / (top + 1),
+                         histogram_forward_plus_backward={"bin_width": 4, "counts": np.bincount(tot // 4).tolist()},
+                         max=int(tot.max()), criteria_max_count=cfg["criteria"][1])
 
-    # max over ranks of the elapsed time; the one collective of the path: RCCL all-gather of the per-rank
-    # feature counts (sharding.gather_counts, also exercised under gloo in tests/test_host_logic.py)
-    tracked_all = [tracked]
+        # gray conversion alone (K1; HBM-bound stream): a 3-channel device image of the frame size
+        rgb = torch.randint(0, 256, (h, w, 3), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        for rep in range(6):
+            ctx.cvt_bgr_device(sl[-1], rgb.data_ptr(), w, h, 3 * w)   # overwrites that slot: nothing reads it afterwards
+        ctx.sync()
+        ctx.prof_enable(False)
+        alone["bgr2gray"] = ctx.prof_table().get("bgr2gray")
+        del rgb
+    # ---- C3: the same 64 pairs once more, every frame crossing PCIe from pinned host memory ------------------------------
+    if cname == "c3" and rank == 0:
+        import ctypes
+        pinned = []
+        for i in range(W, ring):
+            img = np.ascontiguousarray(ctx.download_level(i, 0))
+            ptr = ctx.host_alloc(w * h)
+            ctypes.memmove(ptr, img.ctypes.data, w * h)
+            pinned.append(ptr)
+        ctx.close()   # one handle (four streams) on the device at a time
+        ctx = None
+        hctx = Context(w, h, n_slots=6, max_pts=max_pts, device=local_rank)
+        ht = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=hctx, lookahead=not args.no_lookahead)
+        depth = 3   # uploads in flight ahead of the frame being tracked (6 slots: previous, current, three coming, one spare)
+        hctx.sync()
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        for i in range(min(depth, len(pinned))):
+            ht.prefetch_pinned(pinned[i], w)
+        for i in range(len(pinned)):
+            if i + depth < len(pinned):
+                ht.prefetch_pinned(pinned[i + depth], w)
+            ht.push_prefetched(wait=False)
+        hctx.sync()
+        torch.cuda.synchronize()
+        h1 = time.perf_counter()
+        _, htracked = ht.live()
+        # same frames, same loop: the survivors must agree with the resident run
+        pcie = dict(value=(len(pinned) - 1) / (h1 - h0), unit="frame-pairs/s", pairs=len(pinned) - 1,
+                    tracked_features_per_sec=htracked / (h1 - h0), live_tracks_equal_resident_run=bool(ht.live()[0] == n_live),
+                    source="pinned host memory, hipMemcpyAsync, %d uploads in flight ahead of the tracker (6 slots)" % depth,
+                    bytes_per_frame=w * h, note="includes the first frame's upload and the first (blocking) detection")
+        for ptr in pinned:
+            hctx.host_free(ptr)
+        hctx.close()
+
+    # ---- the collectives of the path: per-segment track counts and the padded track tables, over RCCL -------------------
+    tracked_all, gather = [tracked], None
     if dist is not None:
-        from iceberg_tracking_code_amd import sharding
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        gather_backend = "rccl"
-        try:
-            rccl = dist.new_group(backend="nccl")     # RCCL over xGMI
-            tracked_all = [int(v) for v in sharding.gather_counts([tracked], dist, device="cuda", group=rccl)]
-        except Exception as exc:                      # the line is still worth printing: same counts over gloo
-            sys.stderr.write("RCCL gather failed (%s); using gloo\n" % exc)
-            gather_backend = "gloo (RCCL failed)"
-            tracked_all = [int(v) for v in sharding.gather_counts([tracked], dist)]
+        seg_counts = archive["counts"][:archive["n"]].cpu().numpy().tolist() if archive else [tracked]
+        share = os.environ.get("ICELK_BENCH_SHARED_DEVICE")   # tools/two_rank.sh: both ranks on one GPU, RCCL cannot form
+        ok, err, backend = True, "", "rccl"
+        g0 = time.perf_counter()
+        res_counts, res_tables = None, None
+        if share:
+            ok, backend = True, "gloo (RCCL leg skipped: ranks share a device)"
+        else:
+            try:
+                rccl = dist.new_group(backend="nccl")     # RCCL over xGMI
+                res_counts = sharding.gather_counts(seg_counts + [tracked], dist, device="cuda", group=rccl)
+                if archive:
+                    res_tables = sharding.gather_tables(archive["tracks"][:max(archive["n"], 1)], archive["counts"][:max(archive["n"], 1)],
+                                                        dist, group=rccl)
+                torch.cuda.synchronize()
+            except Exception as exc:
+                ok, err = False, "%s: %s" % (type(exc).__name__, exc)
+                sys.stderr.write("rank %d: RCCL gather failed (%s)\n" % (rank, err))
+        # every rank must take the same branch: agree on the outcome over the control group before touching it
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        all_ok = bool(flag.item())
+        if share or not all_ok:
+            if not share:
+                backend = "gloo (RCCL failed)"
+            res_counts = sharding.gather_counts(seg_counts + [tracked], dist)
+            if archive:
+                res_tables = sharding.gather_tables(archive["tracks"][:max(archive["n"], 1)].cpu(),
+                                                    archive["counts"][:max(archive["n"], 1)].cpu(), dist)
+        g1 = time.perf_counter()
+        # each rank appended its feature total behind its segment counts
+        per_rank = len(seg_counts) + 1
+        rc = np.asarray(res_counts, np.int64).reshape(world, per_rank) if len(res_counts) == world * per_rank else None
+        tracked_all = rc[:, -1].tolist() if rc is not None else [tracked]
+        gather = dict(backend=backend, ok=bool(all_ok or share), seconds=g1 - g0, error=err or None,
+                      segments=int(sum(len(seg_counts) for _ in range(world))) if archive else 0,
+                      tracks_in_tables=int(sum(n for _, n in res_tables)) if res_tables is not None else None,
+                      table_bytes_per_rank=int(archive["tracks"][:max(archive["n"], 1)].numel() * 4) if archive else 0)
+        if res_tables is not None and rc is not None:
+            gather["tables_match_counts"] = bool([n for _, n in res_tables] == rc[:, :-1].reshape(-1).tolist())
 
+    exit_code = 0
     if rank == 0:
         top = top_level_of(w, h, cfg["win"], cfg["max_level"])
         pairs_per_s = world * K / elapsed
@@ -284,23 +508,33 @@ def main():
             "config": {"workload": cfg["name"], "width": w, "height": h, "max_corners": cfg["max_corners"],
                        "win": list(cfg["win"]), "maxLevel": cfg["max_level"], "pyramid_images": top + 1,
                        "criteria": list(cfg["criteria"]), "track_len": TRACK_LEN, "detector": DETECT,
-                       "frames_resident": ring,
-                       "source": "pinned host memory, hipMemcpyAsync double-buffered" if host else "HBM-resident",
-                       "sharding": "independent segments per rank, no data-path collective",
-                       "count_gather": gather_backend if dist is not None else None},
+                       "frames_resident": ring, "source": "HBM-resident",
+                       "motion": "sub-pixel translation (<= 3 px/frame) + affine deformation (<= 0.5 %)" if args.motion == "shear"
+                                 else "sub-pixel translation (<= 3 px/frame) only",
+                       "sharding": "one sequence of %d frames, segment blocks per rank (sharding.frame_block), no data-path "
+                                   "collective" % (world * K + 1) if linear and world > 1 else "single process",
+                       "count_gather": gather["backend"] if gather else None},
         }
+        if gather:
+            out["gather"] = gather
+            out["count_gather_ok"] = gather["ok"]
+            if not gather["ok"]:
+                exit_code = 3
+        if pcie:
+            out["pcie_inclusive"] = pcie
         kern = {}
         lkp = prof.get("lk_fb")
         if lkp:
             n_avg = tracked / max(lkp["launches"], 1)
             alg = 2.0 * lk_algorithmic_bytes(w, h, cfg["win"], top, n_avg)   # forward + backward
             ach = alg / (lkp["avg_us"] * 1e-6) / 1e9
-            out["roofline"] = {"kernel": "k_lk<fb> (fused forward+backward pyramidal LK, all levels)",
+            out["roofline"] = {"kernel": "k_lk_fast<fb> (fused forward+backward pyramidal LK, all levels)",
                                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                "algorithmic_bytes_per_launch": alg, "avg_launch_us": lkp["avg_us"],
                                "features_per_launch": n_avg,
-                               "note": "LK is LDS/VALU-bound (SURVEY.md 8d); HBM fraction reported for completeness"}
+                               "note": "LK is VALU-issue-bound (SURVEY.md 8d); HBM fraction reported for completeness, the "
+                                       "issue fraction is in valu_issue"}
         pd = prof.get("pyrdown")
         if pd:
             alg = pyramid_algorithmic_bytes(w, h, top)
@@ -308,49 +542,68 @@ def main():
             kern["pyramid"] = {"bound": "hbm", "algorithmic_bytes_per_frame": alg, "us_per_frame": per_frame_us,
                                "achieved_GBps": alg / (per_frame_us * 1e-6) / 1e9,
                                "frac": alg / (per_frame_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
-            if "pyrdown" in alone:
+            if alone.get("pyrdown"):
                 a_us = alone["pyrdown"]["total_ms"] * 1e3 / 5.0
                 kern["pyramid"].update(alone_us_per_frame=a_us, alone_GBps=alg / (a_us * 1e-6) / 1e9,
                                        alone_frac=alg / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+        if alone.get("bgr2gray"):
+            alg = 4.0 * w * h
+            a_us = alone["bgr2gray"]["avg_us"]
+            kern["bgr2gray"] = {"bound": "hbm", "algorithmic_bytes_per_frame": alg, "alone_us": a_us,
+                                "alone_GBps": alg / (a_us * 1e-6) / 1e9, "alone_frac": alg / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         eg = prof.get("corner_candidates")
         if eg:
             alg = 1.0 * w * h   # 1 B/px in; the eigenvalue map is never materialised (k_corners.hip)
             kern["corner_candidates"] = {"bound": "hbm", "algorithmic_bytes_per_launch": alg, "avg_launch_us": eg["avg_us"],
-                               "achieved_GBps": alg / (eg["avg_us"] * 1e-6) / 1e9,
-                               "frac": alg / (eg["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                               "note": "f64 box sums: issue-bound, not HBM-bound (DESIGN.md 4.2)"}
-            if "corner_candidates" in alone:
+                                         "achieved_GBps": alg / (eg["avg_us"] * 1e-6) / 1e9,
+                                         "frac": alg / (eg["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                         "note": "f64 box sums: issue-bound, not HBM-bound (DESIGN.md 4.2)"}
+            if alone.get("corner_candidates"):
                 a_us = alone["corner_candidates"]["avg_us"]
                 kern["corner_candidates"].update(alone_us=a_us, alone_GBps=alg / (a_us * 1e-6) / 1e9,
                                                  alone_frac=alg / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
-        if lkp and "lk_fb" in alone:
+        if lkp and alone.get("lk_fb"):
             kern["lk_fb"] = {"bound": "valu issue", "avg_launch_us": lkp["avg_us"], "alone_us": alone["lk_fb"]["avg_us"]}
         out["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2)} for k, v in prof.items()}
         out["kernel_rooflines"] = kern
-        traffic_file = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
-        if "roofline" in out and os.path.exists(traffic_file):
+        if iters:
+            out["iterations_per_feature"] = iters
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_%s.json" % cname)
+        if "roofline" in out and os.path.exists(pmc_file):
+            # counters of THIS kernel from rocprofv3 --pmc runs of `python3 bench.py` (tools/collect_profiles.sh writes the
+            # file; profiles/ holds the raw summaries it was made from)
             try:
-                tj = json.load(open(traffic_file))
-                out["roofline"]["traffic"] = tj.get("lk_fb_bytes_per_launch")
-                out["roofline"]["traffic_source"] = tj.get("source")
-                if tj.get("lk_fb_valu_insts_per_launch") and tj.get("valu_issue_peak_per_s"):
-                    # the bound this kernel actually runs into: VALU issue (PMC SQ_INSTS_VALU per launch, same file)
-                    rate = tj["lk_fb_valu_insts_per_launch"] / (out["roofline"]["avg_launch_us"] * 1e-6)
-                    out["roofline"]["valu_issue"] = {"wave_instructions_per_launch": tj["lk_fb_valu_insts_per_launch"],
-                                                     "achieved_per_s": rate, "peak_per_s": tj["valu_issue_peak_per_s"],
-                                                     "frac": rate / tj["valu_issue_peak_per_s"],
-                                                     "peak_source": tj.get("valu_issue_peak_source")}
-            except Exception:
-                pass
+                pj = json.load(open(pmc_file))
+                out["roofline"]["traffic"] = pj.get("lk_fb_bytes_per_launch")
+                out["roofline"]["traffic_source"] = pj.get("source")
+                vi = pj.get("lk_fb_valu_insts_per_launch")
+                if vi:
+                    rate = vi / (out["roofline"]["avg_launch_us"] * 1e-6)
+                    cyc = pj.get("valu_cycles_per_inst", {})
+                    out["roofline"]["valu_issue"] = {
+                        "wave_instructions_per_launch": vi, "salu_instructions_per_launch": pj.get("lk_fb_salu_insts_per_launch"),
+                        "achieved_per_s": rate,
+                        "peak_per_s": {k: SIMDS * CLOCK_HZ / v for k, v in cyc.items()},
+                        "frac": {k: rate / (SIMDS * CLOCK_HZ / v) for k, v in cyc.items()},
+                        "peak_source": pj.get("valu_cycles_source"),
+                        "valu_busy_pct": pj.get("lk_fb_valu_busy_pct"), "lds_bank_conflict_ratio": pj.get("lk_fb_lds_bank_conflict_ratio"),
+                        "waves_per_simd": pj.get("lk_fb_waves_per_simd"), "vgprs": pj.get("lk_fb_vgprs"),
+                        "sgpr_spills": pj.get("lk_fb_sgpr_spills")}
+            except Exception as exc:
+                sys.stderr.write("profiles/pmc_%s.json unreadable: %s\n" % (cname, exc))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.motion)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
+        code = torch.tensor([exit_code], dtype=torch.int32)
+        dist.broadcast(code, src=0)
+        exit_code = int(code.item())
         dist.barrier()
         dist.destroy_process_group()
-    for ptr in pinned:
-        ctx.host_free(ptr)
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -37,6 +37,7 @@ SIGNATURES = {
     "icelk_host_alloc": (C.c_int, [C.POINTER(vp), C.c_uint64]),
     "icelk_host_free": (C.c_int, [vp]),
     "icelk_synth_frame": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_uint32]),
+    "icelk_synth_frame_affine": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_uint32, i32p]),
     "icelk_drop_pyramid": (C.c_int, [handle_p, C.c_int]),
     "icelk_download_level": (C.c_int, [handle_p, C.c_int, C.c_int, u8p, C.c_int, i32p, i32p]),
     "icelk_build_pyramid": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_int, i32p]),
@@ -65,6 +66,7 @@ SIGNATURES = {
     "icelk_seg_track_async": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_double, C.c_double, C.c_float]),
     "icelk_seg_live": (C.c_int, [handle_p, i32p, i64p]),
+    "icelk_seg_archive": (C.c_int, [handle_p, vp, vp, vp, C.c_int, i32p]),
     "icelk_project_tracks": (C.c_int, [handle_p, f32p, C.c_int, C.c_int, vp, vp, f64p, f64p, f64p, f64p, f64p, u8p]),
     "icelk_seg_project": (C.c_int, [handle_p, vp, vp, C.c_int, C.c_int, f64p, f64p, f64p, f64p, f64p, u8p, i32p, i32p]),
     "icelk_points_in_polygon": (C.c_int, [handle_p, f64p, C.c_int, f64p, C.c_int, u8p]),

@@ -131,8 +131,13 @@ class Context:
     def host_free(self, ptr):
         self._ck(self._lib.icelk_host_free(C.c_void_p(ptr)))
 
-    def synth_frame(self, slot, w, h, ux=0, uy=0, seed=1234):
-        self._ck(self._lib.icelk_synth_frame(self._h, slot, w, h, int(ux), int(uy), int(seed)))
+    def synth_frame(self, slot, w, h, ux=0, uy=0, seed=1234, affine=None):
+        """Procedural frame on the device (bit-identical to synth.frame); `affine` = (ax, bx, ay, by) in 2^-20 px/px."""
+        if affine is None:
+            self._ck(self._lib.icelk_synth_frame(self._h, slot, w, h, int(ux), int(uy), int(seed)))
+            return
+        a = (C.c_int32 * 4)(*[int(v) for v in affine])
+        self._ck(self._lib.icelk_synth_frame_affine(self._h, slot, w, h, int(ux), int(uy), int(seed), a))
 
     def drop_pyramid(self, slot):
         self._ck(self._lib.icelk_drop_pyramid(self._h, slot))
@@ -285,6 +290,14 @@ class Context:
         n, tot = C.c_int(0), C.c_int64(0)
         self._ck(self._lib.icelk_seg_live(self._h, C.byref(n), C.byref(tot)))
         return n.value, tot.value
+
+    def seg_archive(self, dev_tracks_ptr, dev_quality_ptr, dev_count_ptr, cap_rows):
+        """Gather the current segment's surviving tracks into device memory of the caller (no wait); returns the
+        vertex count the rows have."""
+        nv = C.c_int(0)
+        self._ck(self._lib.icelk_seg_archive(self._h, C.c_void_p(dev_tracks_ptr), C.c_void_p(dev_quality_ptr or 0),
+                                             C.c_void_p(dev_count_ptr), int(cap_rows), C.byref(nv)))
+        return nv.value
 
     def seg_read(self):
         """(tracks (n, V, 2) f32, trackquality (n, V-1) f32): what np.savez stores at s1:394-395."""

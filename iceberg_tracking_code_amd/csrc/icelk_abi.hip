@@ -1031,17 +1031,21 @@ int icelk_cvt_bgr_device(icelk_t* h, int slot, const void* dev_bgr, int w, int h
     return ICELK_OK;
 }
 
-int icelk_synth_frame(icelk_t* h, int slot, int w, int h_, int64_t ux, int64_t uy, uint32_t seed)
+int icelk_synth_frame_affine(icelk_t* h, int slot, int w, int h_, int64_t ux, int64_t uy, uint32_t seed,
+                             const int32_t* affine)
 {
     if (!h) return ICELK_EARG;
     Ctx* c = C(h);
     HIPCHK(c, hipSetDevice(c->device));
+    if (affine)
+        for (int k = 0; k < 4; k++)
+            if (affine[k] > (1 << 13) || affine[k] < -(1 << 13)) FAIL(c, ICELK_EARG, "affine coefficient beyond +-2^-7");
     int rc = begin_frame(c, slot, w, h_);
     if (rc) return rc;
     Slot& s = c->slots[slot];
     {
         ProfScope p(c, K_SYNTH);
-        launch_synth(c->stream, s.lv[0], ux, uy, seed);
+        launch_synth(c->stream, s.lv[0], ux, uy, seed, affine);
     }
     rc = check_launch(c, "synth");
     if (rc) return rc;
@@ -1049,6 +1053,11 @@ int icelk_synth_frame(icelk_t* h, int slot, int w, int h_, int64_t ux, int64_t u
     s.levels_built = 1;
     s.pending = false;
     return ICELK_OK;
+}
+
+int icelk_synth_frame(icelk_t* h, int slot, int w, int h_, int64_t ux, int64_t uy, uint32_t seed)
+{
+    return icelk_synth_frame_affine(h, slot, w, h_, ux, uy, seed, nullptr);
 }
 
 int icelk_drop_pyramid(icelk_t* h, int slot)
@@ -1725,6 +1734,29 @@ int icelk_seg_read(icelk_t* h, float* tracks, float* quality, int cap, int max_v
         HIPCHK(c, hipMemcpy2DAsync(quality, sizeof(float) * (max_vertices - 1), c->d_out_quality, sizeof(float) * (nv - 1),
                                    sizeof(float) * (nv - 1), n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICELK_OK;
+}
+
+int icelk_seg_archive(icelk_t* h, void* dev_tracks, void* dev_quality, void* dev_count, int cap_rows, int* out_vertices)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->seg_active) FAIL(c, ICELK_ESTATE, "icelk_seg_detect has not been called");
+    if (!dev_tracks || !dev_count) FAIL(c, ICELK_EARG, "null device buffer");
+    if (cap_rows < c->seg_upper) FAIL(c, ICELK_ECAP, "archive rows < tracks of the segment");
+    int rc = seg_wait(c);
+    if (rc) return rc;
+    const int nv = c->seg_vert;
+    if (out_vertices) *out_vertices = nv;
+    Ctx::SegBuf& S = c->sb[c->sb_cur];
+    // quality is optional: the gather kernel writes it next to the tracks; without a destination it goes to the
+    // handle's own read-out buffer
+    launch_seg_gather(c->stream, S.alive, c->seg_upper, S.tracks, S.quality, nv, kMaxVert, reinterpret_cast<float*>(dev_tracks),
+                      dev_quality ? reinterpret_cast<float*>(dev_quality) : c->d_out_quality, reinterpret_cast<int*>(dev_count));
+    rc = check_launch(c, "seg_archive");
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(S.used, c->stream));
     return ICELK_OK;
 }
 

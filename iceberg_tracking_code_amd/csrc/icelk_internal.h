@@ -77,7 +77,7 @@ struct Ctx;  // full definition in icelk_abi.hip
 void launch_bgr2gray(hipStream_t s, const uint8_t* src, int src_pitch, uint8_t* dst, int dst_pitch,
                      int w, int h, int variant);
 void launch_pyrdown(hipStream_t s, const Level& src, const Level& dst);
-void launch_synth(hipStream_t s, const Level& dst, int64_t ux, int64_t uy, uint32_t seed);
+void launch_synth(hipStream_t s, const Level& dst, int64_t ux, int64_t uy, uint32_t seed, const int* affine);
 
 // LK.  p_in/p_out etc. are device pointers.  fb = fused forward+backward.
 struct LKBuffers {
@@ -191,7 +191,7 @@ void launch_seg_stats(hipStream_t s, const uint8_t* alive, int n, const unsigned
                       unsigned long long* host_out);
 // rows of the alive tracks, in track order, packed into out_tracks (n_alive, nvert, 2) / out_quality
 void launch_seg_gather(hipStream_t s, const uint8_t* alive, int n, const float* tracks, const float* quality,
-                       int nvert, int max_vert, float* out_tracks, float* out_quality);
+                       int nvert, int max_vert, float* out_tracks, float* out_quality, int* out_count = nullptr);
 size_t min_eig_lds_bytes(int block_size);
 
 }  // namespace icelk

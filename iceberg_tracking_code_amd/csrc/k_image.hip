@@ -198,16 +198,20 @@ __device__ __forceinline__ uint32_t octave(uint32_t X, uint32_t Y, int k, uint32
     return (top * (256u - sy) + bot * sy) >> 16;
 }
 
+// The frame is the texture sampled at  X = x0 + 256 x + ((ax x + bx y) >> 12),  Y = y0 + 256 y + ((ay x + by y) >> 12)
+// (1/256 px; ax.. in 2^-20 px per px): a translation plus, optionally, a small affine deformation (shear / scale /
+// rotation of a fraction of a percent), so that the motion differs from place to place in the frame.
 __global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ dst, int w, int h, int pitch, uint32_t x0,
-                                               uint32_t y0, uint32_t seed)
+                                               uint32_t y0, uint32_t seed, int ax, int bx, int ay, int by)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (4 * q >= w || y >= h) return;
-    const uint32_t Y = y0 + ((uint32_t)y << 8);
     uint32_t out = 0;
     for (int i = 0; i < 4; i++) {
-        const uint32_t X = x0 + ((uint32_t)(4 * q + i) << 8);
+        const int x = 4 * q + i;
+        const uint32_t X = x0 + ((uint32_t)x << 8) + (uint32_t)((ax * x + bx * y) >> 12);
+        const uint32_t Y = y0 + ((uint32_t)y << 8) + (uint32_t)((ay * x + by * y) >> 12);
         uint32_t acc = 3u * octave(X, Y, 3, seed) + 3u * octave(X, Y, 5, seed) + 2u * octave(X, Y, 2, seed);
         out |= ((acc >> 3) & 255u) << (8 * i);
     }
@@ -217,14 +221,15 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ dst, int w,
         for (int i = 0; 4 * q + i < w; i++) d[i] = (uint8_t)(out >> (8 * i));
 }
 
-void launch_synth(hipStream_t s, const Level& dst, int64_t ux, int64_t uy, uint32_t seed)
+void launch_synth(hipStream_t s, const Level& dst, int64_t ux, int64_t uy, uint32_t seed, const int* affine)
 {
     const int64_t bias = (int64_t)1 << 16;
     const uint32_t x0 = (uint32_t)((bias << 8) + ux);
     const uint32_t y0 = (uint32_t)((bias << 8) + uy);
     dim3 block(256);
     dim3 grid(((dst.w + 3) / 4 + 255) / 256, dst.h);
-    hipLaunchKernelGGL(k_synth, grid, block, 0, s, dst.ptr, dst.w, dst.h, dst.pitch, x0, y0, seed);
+    hipLaunchKernelGGL(k_synth, grid, block, 0, s, dst.ptr, dst.w, dst.h, dst.pitch, x0, y0, seed, affine ? affine[0] : 0,
+                       affine ? affine[1] : 0, affine ? affine[2] : 0, affine ? affine[3] : 0);
 }
 
 }  // namespace icelk

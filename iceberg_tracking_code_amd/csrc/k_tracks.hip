@@ -108,7 +108,8 @@ __global__ __launch_bounds__(1024) void k_seg_stats(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(1024) void k_seg_gather(const uint8_t* __restrict__ alive, int n,
                                                      const float* __restrict__ tracks,
                                                      const float* __restrict__ quality, int nvert, int max_vert,
-                                                     float* __restrict__ out_tracks, float* __restrict__ out_quality)
+                                                     float* __restrict__ out_tracks, float* __restrict__ out_quality,
+                                                     int* __restrict__ out_count)
 {
     __shared__ int wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(1024) void k_seg_gather(const uint8_t* __restrict__
         running += tile_total;
         __syncthreads();
     }
+    if (out_count && tid == 0) *out_count = running;
 }
 
 // the forward-backward filter of s1:329-333 on its own: the same device function the fused tracker launches end with
@@ -191,11 +193,14 @@ void launch_seg_stats(hipStream_t s, const uint8_t* alive, int n, const unsigned
 }
 
 void launch_seg_gather(hipStream_t s, const uint8_t* alive, int n, const float* tracks, const float* quality,
-                       int nvert, int max_vert, float* out_tracks, float* out_quality)
+                       int nvert, int max_vert, float* out_tracks, float* out_quality, int* out_count)
 {
-    if (n <= 0) return;
+    if (n <= 0) {
+        if (out_count) hipMemsetAsync(out_count, 0, sizeof(int), s);
+        return;
+    }
     hipLaunchKernelGGL(k_seg_gather, dim3(1), dim3(1024), 0, s, alive, n, tracks, quality, nvert, max_vert, out_tracks,
-                       out_quality);
+                       out_quality, out_count);
 }
 
 }  // namespace icelk

@@ -55,3 +55,42 @@ def gather_counts(local_counts, dist=None, device=None, group=None):
     parts = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine, group=group)
     return np.concatenate([p[:k].cpu().numpy() for p, k in zip(parts, sizes)]) if sum(sizes) else np.zeros(0, np.int64)
+
+
+def gather_tables(tracks, counts, dist=None, group=None):
+    """All ranks' per-segment track tables (the `tracks` arrays of s1:394-395), in rank order.
+
+    tracks: torch tensor (S, R, V, 2) float32 -- S segments of this rank, each padded to R rows, the first counts[s]
+    rows valid; counts: torch tensor (S,) int32/int64 on the same device.  Every rank passes the same R and V; S may
+    differ by one (segment_block), so blocks are padded to the largest S.  Two all_gathers (counts, then tables): with
+    backend "nccl" that is RCCL over xGMI, and the only exchange of a sharded run.  Returns a list with one
+    (first_rows, n) numpy pair per segment of the whole sequence: [(tracks[:n], n), ...].
+    """
+    import torch
+    S = int(tracks.shape[0])
+    world = 1 if dist is None or not dist.is_initialized() else dist.get_world_size()
+    if world == 1:
+        c = counts.cpu().numpy().astype(np.int64)
+        t = tracks.cpu().numpy()
+        return [(t[s, :c[s]].copy(), int(c[s])) for s in range(S)]
+    dev = tracks.device
+    n_seg = torch.tensor([S], dtype=torch.int64, device=dev)
+    all_seg = [torch.zeros_like(n_seg) for _ in range(world)]
+    dist.all_gather(all_seg, n_seg, group=group)
+    all_seg = [int(v.item()) for v in all_seg]
+    pad = max(max(all_seg), 1)
+    cpad = torch.zeros(pad, dtype=torch.int64, device=dev)
+    cpad[:S] = counts.to(torch.int64)
+    tpad = torch.zeros((pad,) + tuple(tracks.shape[1:]), dtype=tracks.dtype, device=dev)
+    tpad[:S] = tracks
+    call = [torch.zeros_like(cpad) for _ in range(world)]
+    tall = [torch.zeros_like(tpad) for _ in range(world)]
+    dist.all_gather(call, cpad, group=group)
+    dist.all_gather(tall, tpad, group=group)
+    out = []
+    for r in range(world):
+        c = call[r].cpu().numpy()
+        t = tall[r].cpu().numpy()
+        for s in range(all_seg[r]):
+            out.append((t[s, :c[s]].copy(), int(c[s])))
+    return out

@@ -48,15 +48,23 @@ def _octave(X, Y, k, seed):
     return (top * (c256 - sy) + bot * sy) >> np.uint32(16)
 
 
-def frame(width, height, ux=0, uy=0, seed=1234, rows=None):
-    """One HxW uint8 frame shifted by (ux, uy)/256 px.  `rows=(y0, y1)` renders a band only."""
+AFFINE_BITS = 20           # affine coefficients are in 2^-20 px per px
+
+
+def frame(width, height, ux=0, uy=0, seed=1234, rows=None, affine=None):
+    """One HxW uint8 frame shifted by (ux, uy)/256 px.  `rows=(y0, y1)` renders a band only.  `affine` = (ax, bx, ay, by)
+    adds (ax x + bx y, ay x + by y) / 2^20 px to the sample position: a deformation that varies over the frame."""
     y0, y1 = (0, height) if rows is None else rows
-    xs = ((np.arange(width, dtype=np.int64) + BIAS_PX) << FRAC_BITS) + int(ux)
-    ys = ((np.arange(y0, y1, dtype=np.int64) + BIAS_PX) << FRAC_BITS) + int(uy)
+    xi = np.arange(width, dtype=np.int64)[None, :]
+    yi = np.arange(y0, y1, dtype=np.int64)[:, None]
+    ax, bx, ay, by = (0, 0, 0, 0) if affine is None else (int(v) for v in affine)
+    sh = AFFINE_BITS - FRAC_BITS
+    xs = ((xi + BIAS_PX) << FRAC_BITS) + int(ux) + ((ax * xi + bx * yi) >> sh)
+    ys = ((yi + BIAS_PX) << FRAC_BITS) + int(uy) + ((ay * xi + by * yi) >> sh)
     if xs.min() < 0 or ys.min() < 0 or xs.max() >= 1 << 32 or ys.max() >= 1 << 32:
         raise ValueError("shift out of range")
-    X = np.broadcast_to(xs.astype(np.uint32)[None, :], (y1 - y0, width))
-    Y = np.broadcast_to(ys.astype(np.uint32)[:, None], (y1 - y0, width))
+    X = np.broadcast_to(xs, (y1 - y0, width)).astype(np.uint32)
+    Y = np.broadcast_to(ys, (y1 - y0, width)).astype(np.uint32)
     acc = np.zeros((y1 - y0, width), np.uint32)
     for k, wgt in _OCTAVES:
         acc += np.uint32(wgt) * _octave(X, Y, k, seed)
@@ -71,6 +79,18 @@ def shifts(n_frames, seed=1234, max_step_px=3.0):
     out = np.zeros((n_frames, 2), np.int64)
     if n_frames > 1:
         out[1:] = np.cumsum(steps, axis=0)
+    return out
+
+
+def affines(n_frames, seed=1234, max_coef=0.005, step=0.0015):
+    """Per-frame affine coefficients (ax, bx, ay, by) in 2^-20 px/px: a seeded random walk of steps <= `step`, kept
+    within +-`max_coef` (0.5 %: SURVEY.md 8d "smooth shear <= 0.5 %"); frame 0 is undeformed."""
+    rng = np.random.RandomState(seed + 17)
+    one = 1 << AFFINE_BITS
+    m, st = int(round(max_coef * one)), int(round(step * one))
+    out = np.zeros((n_frames, 4), np.int64)
+    for i in range(1, n_frames):
+        out[i] = np.clip(out[i - 1] + rng.randint(-st, st + 1, size=4), -m, m)
     return out
 
 

@@ -178,6 +178,7 @@ class SegmentTracker:
         self.lookahead = bool(lookahead)
         self._pyr_ahead = None    # slot whose pyramid was enqueued ahead of its step
         self._resident = False    # inside push_slot
+        self.on_close = None      # callable(first_frame) invoked when a segment closes, before the switch to the next
         self._det_for = None      # frame counter whose detection (min-distance stage) is in flight
         self._prepared_for = None  # frame counter whose corner candidates have been prepared ahead
         self._staged = False      # a new segment waits in the spare set for the switch
@@ -295,6 +296,8 @@ class SegmentTracker:
             self._staged = True
             self._det_for = None
         if detect:
+            if c > 0 and self.on_close is not None:
+                self.on_close(self.seg_first)     # e.g. ctx.seg_archive(...) of the closing segment, still current here
             if c > 0 and wait:
                 tracks, quality = self.ctx.seg_read()
                 out = (self.seg_first, tracks, quality)

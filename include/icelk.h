@@ -97,6 +97,11 @@ int icelk_host_free(void* p);
 /* procedural frame generated on the device (integer value noise, bit-identical to
  * iceberg_tracking_code_amd/synth.py); ux,uy = shift in 1/256 px. */
 int icelk_synth_frame(icelk_t* h, int slot, int w, int h_, int64_t ux, int64_t uy, uint32_t seed);
+/* the same with a small affine deformation on top of the shift: the texture is sampled at
+ * x + ux/256 + (a[0] x + a[1] y) / 2^20,  y + uy/256 + (a[2] x + a[3] y) / 2^20  (|a[k]| <= 2^13, i.e. 0.8 %), so the
+ * motion between two frames varies over the frame (shear / scale / rotation); NULL = none. */
+int icelk_synth_frame_affine(icelk_t* h, int slot, int w, int h_, int64_t ux, int64_t uy, uint32_t seed,
+                             const int32_t* affine);
 /* Forget levels >= 1 of a slot whose level 0 stays resident, so the next tracker call rebuilds the
  * pyramid (a frame that is already in HBM re-enters the loop without a copy). */
 int icelk_drop_pyramid(icelk_t* h, int slot);
@@ -186,6 +191,12 @@ int icelk_seg_track(icelk_t* h, int slot_prev, int slot_next, int win_w, int win
  * dimension. */
 int icelk_seg_read(icelk_t* h, float* tracks, float* quality, int cap, int max_vertices, int* out_n,
                    int* out_vertices);
+/* The same gather into DEVICE memory of the caller (e.g. one slice of a torch tensor that is all-gathered over RCCL at
+ * the end of a sharded run, BASELINE.json configs[3]): rows of the surviving tracks, packed, (n, n_vertices, 2) float32
+ * at dev_tracks, (n, n_vertices-1) at dev_quality (may be NULL), n as one int32 at dev_count.  cap_rows = rows the
+ * buffers hold, must be >= the tracks the segment started with.  Enqueued on the handle's compute stream: no wait, no
+ * host read-back. */
+int icelk_seg_archive(icelk_t* h, void* dev_tracks, void* dev_quality, void* dev_count, int cap_rows, int* out_vertices);
 /* non-blocking variants for pipelined loops: no host read-back, counts stay on the device */
 int icelk_seg_track_async(icelk_t* h, int slot_prev, int slot_next, int win_w, int win_h, int max_level,
                           int crit_type, int max_count, double epsilon, double min_eig_threshold,

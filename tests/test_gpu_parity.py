@@ -48,6 +48,11 @@ def test_synth_device_equals_numpy(ctx, synth, w, h):
     for ux, uy, seed in [(0, 0, 1234), (300, -200, 1234), (-7777, 12345, 99)]:
         ctx.synth_frame(1, w, h, ux, uy, seed)
         assert np.array_equal(ctx.download_level(1, 0), synth.frame(w, h, ux, uy, seed))
+        for aff in ((0, 0, 0, 0), (5243, -3000, 2000, -5243), (-8192, 8192, 8192, -8192)):
+            ctx.synth_frame(1, w, h, ux, uy, seed, affine=aff)
+            assert np.array_equal(ctx.download_level(1, 0), synth.frame(w, h, ux, uy, seed, affine=aff)), aff
+    with pytest.raises(ValueError):
+        ctx.synth_frame(1, w, h, 0, 0, 1, affine=(9000, 0, 0, 0))
 
 
 def _points(rng, n, w, h, border=-5.0):
