@@ -94,6 +94,7 @@ struct Ctx {
     // latest tracker call; ICELK_NO_BORDER_FIRST=1 turns the class off
     int border_px = (10 + 6 + 2) << 2;
     bool border_first = true;
+    bool pyr_per_level = false;            // ICELK_PYR_PER_LEVEL=1: one pyrDown launch per level (A/B, second statement)
     int fb_dist_form = ICELK_FB_HYPOT;     // icelk_set_fb_distance
     int lk_kernel_flags = 0;               // icelk_set_lk_kernel: ICELK_FLAG_GENERIC_KERNEL / _ONE_PER_WAVE or 0
     // diagnostics: ICELK_LK_STAMPS=<file> records entry / exit time and placement of every workgroup of the LAST
@@ -279,6 +280,26 @@ static int begin_frame(Ctx* c, int slot, int w, int h)
     return ICELK_OK;
 }
 
+// levels levels_built .. top_level of a slot on stream st: up to three levels per launch (k_pyramid.hip); the
+// level-by-level kernel (k_image.hip) stays selectable (ICELK_PYR_PER_LEVEL=1) as the second statement of the arithmetic
+static int build_levels(Ctx* c, Slot& s, int top_level, hipStream_t st)
+{
+    const bool per_level = c->pyr_per_level;
+    while (s.levels_built < top_level + 1) {
+        const int l = s.levels_built;
+        const int n = per_level ? 1 : std::min(3, top_level + 1 - l);
+        {
+            ProfScope p(c, K_PYRDOWN, st);
+            if (per_level) launch_pyrdown(st, s.lv[l - 1], s.lv[l]);
+            else launch_pyramid_fused(st, s.lv, l - 1, n);
+        }
+        int rc = check_launch(c, "pyramid");
+        if (rc) return rc;
+        s.levels_built += n;
+    }
+    return ICELK_OK;
+}
+
 static int ensure_pyramid(Ctx* c, int slot, int top_level)
 {
     Slot& s = c->slots[slot];
@@ -286,16 +307,8 @@ static int ensure_pyramid(Ctx* c, int slot, int top_level)
     if (rc) return rc;
     if (top_level + 1 > kMaxLevels) FAIL(c, ICELK_EARG, "maxLevel too large");
     const bool build = s.levels_built < top_level + 1;
-    while (s.levels_built < top_level + 1) {
-        const int l = s.levels_built;
-        {
-            ProfScope p(c, K_PYRDOWN);
-            launch_pyrdown(c->stream, s.lv[l - 1], s.lv[l]);
-        }
-        rc = check_launch(c, "pyrdown");
-        if (rc) return rc;
-        s.levels_built++;
-    }
+    rc = build_levels(c, s, top_level, c->stream);
+    if (rc) return rc;
     return build ? mark_used(c, slot) : ICELK_OK;
 }
 
@@ -476,7 +489,7 @@ static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
     T.max_key = e.max_key;
     {
         ProfScope p(c, K_EIG, es);
-        launch_candidates(es, T, s.lv[0], block_size, mask, c->mask_pitch, 1.0, false, nullptr, true);
+        launch_candidates(es, T, s.lv[0], block_size, mask, c->mask_pitch, 1.0, false, nullptr);
     }
     rc = check_launch(c, "corner candidates (prepared)");
     if (rc) return rc;
@@ -851,6 +864,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         return fail(rc);
     c->use_order = getenv("ICELK_NO_ORDER") == nullptr;
     c->border_first = getenv("ICELK_NO_BORDER_FIRST") == nullptr;
+    c->pyr_per_level = getenv("ICELK_PYR_PER_LEVEL") != nullptr;
     if (!c->border_first) c->border_px = 0;
     if ((rc = dmalloc(c, &c->d_iters, (size_t)max_pts))) return fail(rc);
     if (const char* sp = getenv("ICELK_LK_STAMPS")) {
@@ -1127,16 +1141,8 @@ int icelk_build_pyramid_ahead(icelk_t* h, int slot, int win_w, int win_h, int ma
     HIPCHK(c, hipStreamWaitEvent(cs, s.frame_ev, 0));
     if (s.pending) HIPCHK(c, hipStreamWaitEvent(cs, s.ready, 0));
     HIPCHK(c, hipStreamWaitEvent(cs, s.used, 0));
-    while (s.levels_built < top + 1) {
-        const int l = s.levels_built;
-        {
-            ProfScope p(c, K_PYRDOWN, cs);
-            launch_pyrdown(cs, s.lv[l - 1], s.lv[l]);
-        }
-        rc = check_launch(c, "pyrdown (ahead)");
-        if (rc) return rc;
-        s.levels_built++;
-    }
+    rc = build_levels(c, s, top, cs);
+    if (rc) return rc;
     HIPCHK(c, hipEventRecord(s.ready, cs));
     s.pending = true;
     return ICELK_OK;

@@ -77,6 +77,8 @@ struct Ctx;  // full definition in icelk_abi.hip
 void launch_bgr2gray(hipStream_t s, const uint8_t* src, int src_pitch, uint8_t* dst, int dst_pitch,
                      int w, int h, int variant);
 void launch_pyrdown(hipStream_t s, const Level& src, const Level& dst);
+// lv[first+1 .. first+n] (n = 1..3) from lv[first] in ONE launch (k_pyramid.hip)
+void launch_pyramid_fused(hipStream_t s, const Level* lv, int first, int n);
 void launch_synth(hipStream_t s, const Level& dst, int64_t ux, int64_t uy, uint32_t seed, const int* affine);
 
 // LK.  p_in/p_out etc. are device pointers.  fb = fused forward+backward.
@@ -143,12 +145,8 @@ void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig,
 bool fused_block_size(int bs);
 void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, bool full);   // full: before launch_candidates
 // K6+K7: local maxima into per-workgroup regions of D.raw (stream order, no host sync)
-// background: the launch is meant to run BEHIND a tracker launch (icelk_seg_detect_prepare): the 70-KB form of the
-// fused kernel is used, whose workgroups only fit where the tracker has drained -- it fills tails instead of competing
-// (3 730 vs 3 600 pairs/s); foreground launches use the 33-KB form (233 vs 337 us alone).
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
-                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null,
-                       bool background = false);
+                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null);
 size_t candidate_capacity(int w, int h);   // keys the region layout needs
 size_t candidate_blocks(int w, int h);
 // minDistance < 1: candidates above the threshold, flat in D.cand / D.cand_count

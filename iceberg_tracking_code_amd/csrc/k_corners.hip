@@ -94,6 +94,35 @@ __device__ __forceinline__ void sobel_cov2(f2 a0, f2 b0, f2 c0, f2 a1, f2 c1, f2
     yy = dy * dy;
 }
 
+// N consecutive window sums of BS terms each over v[0 .. N+BS-2].  Every term is a float product of derivative
+// values of an 8-bit image: magnitudes in [2^-27, 2^-3] with 24-bit mantissas, so ANY sum of up to a few hundred of
+// them is exact in double (tests/test_oracle_kat.py::test_box_sums_of_the_covariance_planes_are_exact_in_double) --
+// a sliding sum (drop the oldest term, add the next) therefore gives bit for bit the value of OpenCV's running
+// RowSum / ColumnSum and of the term-by-term sum the oracle forms, with 2 additions per output instead of BS - 1.
+template <int N, int BS>
+__device__ __forceinline__ void window_sums(const double (&v)[N + BS - 1], double (&out)[N])
+{
+    if constexpr (BS <= 3) {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < BS; k++) s += v[i + k];
+            out[i] = s;
+        }
+    } else {
+        double s = v[0];
+#pragma unroll
+        for (int k = 1; k < BS; k++) s += v[k];
+        out[0] = s;
+#pragma unroll
+        for (int i = 1; i < N; i++) {
+            s = (s - v[i - 1]) + v[i + BS - 1];
+            out[i] = s;
+        }
+    }
+}
+
 __device__ __forceinline__ float min_eig_of(double s0, double s1, double s2)
 {
     const float a = __fmul_rn((float)s0, 0.5f), b = (float)s1, c = __fmul_rn((float)s2, 0.5f);
@@ -122,211 +151,15 @@ struct CandSrc {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Fused K6+K7, compile-time blockSize.
+// Fused K6+K7, compile-time blockSize: 33 KB of LDS, 4 workgroups per CU.  Only the two derivative planes are kept
+// (the covariance products are formed where they are summed, each with the single f32 rounding OpenCV's stored
+// planes have), and the double row sums of ONE plane at a time: row pass -> barrier -> column pass into registers
+// -> barrier, three times.  (A first form that kept all three covariance planes and their row sums -- 70 KB of LDS,
+// 2 workgroups per CU -- took 337 us alone at 12 MP against 120 us for this one, and beside the tracker launch its
+// workgroups waited for whole CUs to drain: 440 us against 177 us.  It is gone.)
 // ------------------------------------------------------------------------------------------------
 template <int BS>
 struct EigCfg {
-    static constexpr int TW = 64, TH = 16;             // outputs per workgroup
-    static constexpr int EW = TW + 2, EH = TH + 2;     // eigenvalues incl. the 1-px ring for the 3x3 test
-    static constexpr int CW = EW + BS - 1, CH = EH + BS - 1;  // covariance positions
-    static constexpr int CWP = (CW + 3) & ~3;          // covariance row pitch (floats)
-    static constexpr int UW = CW + 2, UH = CH + 2;     // u8 source tile
-    static constexpr int UPD = (UW + 2) / 4 + 1;       // its LDS row pitch (dwords, any 4-byte phase)
-    static constexpr int AN = BS / 2;                  // boxFilter anchor
-    static constexpr int RX = 6, RY = 6;               // register blocking of the two sum passes
-    static constexpr int NGX = EW / RX, NGY = EH / RY;
-    static_assert(EW % RX == 0 && EH % RY == 0, "blocking must divide the tile");
-    static constexpr int U_BYTES = (UPD * UH * 4 + 15) & ~15;
-    static constexpr int COV_BYTES = 3 * CH * CWP * 4;
-    static constexpr int A_BYTES = U_BYTES + COV_BYTES;       // later reused for the eigenvalue tile
-    static constexpr int HS_BYTES = 3 * CH * EW * 8;          // later reused for the candidate list
-    static constexpr int LDS_BYTES = A_BYTES + HS_BYTES;
-    static_assert(EW * EH * 4 <= A_BYTES, "eigenvalue tile must fit the dead covariance region");
-};
-
-template <int BS>
-__global__ __launch_bounds__(256) void k_eig_nms(const uint8_t* __restrict__ img, int w, int h, int pitch, float k0,
-                                                 float k1, const uint8_t* __restrict__ mask, int mask_pitch,
-                                                 unsigned* __restrict__ max_key,
-                                                 unsigned long long* __restrict__ raw, int* __restrict__ blk_count,
-                                                 float* __restrict__ eig_out)
-{
-    using C = EigCfg<BS>;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t* U = reinterpret_cast<uint32_t*>(smem);
-    float* cov = reinterpret_cast<float*>(smem + C::U_BYTES);
-    double* hs = reinterpret_cast<double*>(smem + C::A_BYTES);
-    float* E = reinterpret_cast<float*>(smem);                                  // after the row-sum pass
-    __shared__ int s_list_n;
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * C::TW, y0 = blockIdx.y * C::TH;
-    const int ux0 = x0 - 2 - C::AN, uy0 = y0 - 2 - C::AN;   // image coordinate of U(0,0)
-    const bool interior = ux0 >= 0 && uy0 >= 0 && ux0 + C::UW <= w && uy0 + C::UH <= h;
-    constexpr int COVP = C::CH * C::CWP;   // plane stride
-
-    if (interior) {
-        // 1a. stage the source tile as aligned dwords
-        const uint8_t* base = img + (size_t)uy0 * pitch + (ux0 & ~3);
-        for (int i = tid; i < C::UPD * C::UH; i += 256) {
-            const int r = i / C::UPD, c = i - r * C::UPD;
-            U[i] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * c);
-        }
-        __syncthreads();
-        // 1b. covariance products, 4 positions per task over the full quads of a row (18 x 27 tasks = two
-        //     rounds of 256 threads for blockSize 10); the 0..3 leftover columns are done one position per lane
-        const int cs = ux0 & 3;
-        constexpr int NQF = C::CW / 4, REM = C::CW - 4 * NQF;
-        for (int t = tid; t < C::CH * NQF; t += 256) {
-            const int cy = t / NQF, q = t - cy * NQF;
-            int B[3][6];
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const uint32_t* p = U + (cy + r) * C::UPD + ((cs + 4 * q) >> 2);
-                const int sh = (cs + 4 * q) & 3;
-                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-                const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, sh), e1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-                B[r][0] = e0 & 255; B[r][1] = (e0 >> 8) & 255; B[r][2] = (e0 >> 16) & 255; B[r][3] = e0 >> 24;
-                B[r][4] = e1 & 255; B[r][5] = (e1 >> 8) & 255;
-            }
-            float F[3][6];
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int i = 0; i < 6; i++) F[r][i] = (float)B[r][i];
-            f2 xx[2], xy[2], yy[2];
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int j = 2 * i;
-                sobel_cov2(f2{F[0][j], F[0][j + 1]}, f2{F[0][j + 1], F[0][j + 2]}, f2{F[0][j + 2], F[0][j + 3]},
-                           f2{F[1][j], F[1][j + 1]}, f2{F[1][j + 2], F[1][j + 3]},
-                           f2{F[2][j], F[2][j + 1]}, f2{F[2][j + 1], F[2][j + 2]}, f2{F[2][j + 2], F[2][j + 3]},
-                           k0, k1, xx[i], xy[i], yy[i]);
-            }
-            float* c = cov + cy * C::CWP + 4 * q;
-            *reinterpret_cast<float4*>(c) = make_float4(xx[0].x, xx[0].y, xx[1].x, xx[1].y);
-            *reinterpret_cast<float4*>(c + COVP) = make_float4(xy[0].x, xy[0].y, xy[1].x, xy[1].y);
-            *reinterpret_cast<float4*>(c + 2 * COVP) = make_float4(yy[0].x, yy[0].y, yy[1].x, yy[1].y);
-        }
-        if (REM > 0) {
-            const uint8_t* Ub = reinterpret_cast<const uint8_t*>(U);
-            for (int i = tid; i < C::CH * REM; i += 256) {
-                const int cy = i / REM, cx = 4 * NQF + (i - cy * REM);
-                const uint8_t* r0 = Ub + cy * C::UPD * 4 + cs + cx;
-                const uint8_t* r1 = r0 + C::UPD * 4;
-                const uint8_t* r2 = r1 + C::UPD * 4;
-                float xx, xy, yy;
-                sobel_cov((float)r0[0], (float)r0[1], (float)r0[2], (float)r1[0], (float)r1[2], (float)r2[0], (float)r2[1],
-                          (float)r2[2], k0, k1, xx, xy, yy);
-                float* c = cov + cy * C::CWP + cx;
-                c[0] = xx; c[COVP] = xy; c[2 * COVP] = yy;
-            }
-        }
-    } else {
-        // border tiles: covariance at the reflected position (boxFilter reflects the covariance image, Sobel
-        // reflects the source image)
-        for (int i = tid; i < C::CH * C::CW; i += 256) {
-            const int cy = i / C::CW, cx = i - cy * C::CW;
-            const int rx = reflect101(ux0 + 1 + cx, w), ry = reflect101(uy0 + 1 + cy, h);
-            const int xm = reflect101(rx - 1, w), xp = reflect101(rx + 1, w);
-            const int ym = reflect101(ry - 1, h), yp = reflect101(ry + 1, h);
-            const uint8_t* r0 = img + (size_t)ym * pitch;
-            const uint8_t* r1 = img + (size_t)ry * pitch;
-            const uint8_t* r2 = img + (size_t)yp * pitch;
-            float xx, xy, yy;
-            sobel_cov((float)r0[xm], (float)r0[rx], (float)r0[xp], (float)r1[xm], (float)r1[xp], (float)r2[xm],
-                      (float)r2[rx], (float)r2[xp], k0, k1, xx, xy, yy);
-            float* c = cov + cy * C::CWP + cx;
-            c[0] = xx; c[COVP] = xy; c[2 * COVP] = yy;
-        }
-    }
-    __syncthreads();
-
-    // 2. row sums: hs[p][cy][ex] = sum_{k<BS} cov[p][cy][ex+k], left to right, in double
-    //    one (plane, row, 6-output group) per task: 3 x 27 x 11 = 891 tasks fill the 256 threads in 4 rounds
-    constexpr int HSP = C::CH * C::EW;
-    for (int t = tid; t < 3 * C::CH * C::NGX; t += 256) {
-        const int p = t / (C::CH * C::NGX), t2 = t - p * (C::CH * C::NGX);
-        const int cy = t2 / C::NGX, g = t2 - cy * C::NGX;
-        {
-            const float* c = cov + p * COVP + cy * C::CWP + g * C::RX;
-            double v[C::RX + BS - 1];
-#pragma unroll
-            for (int i = 0; i < C::RX + BS - 1; i++) v[i] = (double)c[i];
-            double* o = hs + p * HSP + cy * C::EW + g * C::RX;
-#pragma unroll
-            for (int i = 0; i < C::RX; i++) {
-                double s = 0;
-#pragma unroll
-                for (int k = 0; k < BS; k++) s += v[i + k];
-                o[i] = s;
-            }
-        }
-    }
-    __syncthreads();
-
-    // 3. column sums top to bottom, eigenvalue tile (aliases the covariance region), masked maximum
-    unsigned best = 0;
-    for (int t = tid; t < C::EW * C::NGY; t += 256) {
-        const int g = t / C::EW, ex = t - g * C::EW;
-        double v[3][C::RY + BS - 1];
-#pragma unroll
-        for (int p = 0; p < 3; p++)
-#pragma unroll
-            for (int i = 0; i < C::RY + BS - 1; i++) v[p][i] = hs[p * HSP + (g * C::RY + i) * C::EW + ex];
-#pragma unroll
-        for (int i = 0; i < C::RY; i++) {
-            double s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-            for (int k = 0; k < BS; k++) { s0 += v[0][i + k]; s1 += v[1][i + k]; s2 += v[2][i + k]; }
-            const float e = min_eig_of(s0, s1, s2);
-            const int ey = g * C::RY + i;
-            // E is written only after every thread finished reading hs; cov is dead since the barrier above
-            E[ey * C::EW + ex] = e;
-            const int x = x0 - 1 + ex, y = y0 - 1 + ey;
-            if (ex >= 1 && ex <= C::TW && ey >= 1 && ey <= C::TH && x < w && y < h) {
-                if (eig_out) eig_out[(size_t)y * w + x] = e;
-                if (!mask || mask[(size_t)y * mask_pitch + x]) {
-                    const unsigned k = ordered_key(e);
-                    best = k > best ? k : best;
-                }
-            }
-        }
-    }
-    publish_max(max_key, best, tid);
-    if (tid == 0) s_list_n = 0;
-    __syncthreads();
-
-    // 4. 3x3 non-max test; survivors go straight to this workgroup's region of the candidate buffer
-    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-    unsigned long long* region = raw + (size_t)bid * (C::TW * C::TH);
-    for (int i = tid; i < C::TW * C::TH; i += 256) {
-        const int oy = i / C::TW, ox = i - oy * C::TW;
-        const int x = x0 + ox, y = y0 + oy;
-        if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) continue;
-        const float* e = E + (oy + 1) * C::EW + (ox + 1);
-        const float v = e[0];
-        if (!(v > 0.f)) continue;
-        float m = e[-C::EW - 1];
-        m = fmaxf(m, e[-C::EW]); m = fmaxf(m, e[-C::EW + 1]);
-        m = fmaxf(m, e[-1]); m = fmaxf(m, e[1]);
-        m = fmaxf(m, e[C::EW - 1]); m = fmaxf(m, e[C::EW]); m = fmaxf(m, e[C::EW + 1]);
-        if (v < m) continue;
-        if (mask && !mask[(size_t)y * mask_pitch + x]) continue;
-        region[atomicAdd(&s_list_n, 1)] = ((unsigned long long)ordered_key(v) << 32) | pack_xy(x, y);
-    }
-    __syncthreads();
-    if (tid == 0) blk_count[bid] = s_list_n;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fused K6+K7, second form: the same arithmetic with 33 KB of LDS instead of 70 KB (4 workgroups per CU instead
-// of 2 -- the first form is occupancy-bound: 337 us alone against an issue floor of 110 us).  Only the two
-// derivative planes are kept (the covariance products are formed where they are summed, each with the same single
-// f32 rounding), and the double row sums of ONE plane at a time: row pass -> barrier -> column pass into registers
-// -> barrier, three times.  Sums run in the same order as in the first form, so results are bit-identical.
-// ------------------------------------------------------------------------------------------------
-template <int BS>
-struct EigCfg2 {
     static constexpr int TW = 64, TH = 16;
     static constexpr int EW = TW + 2, EH = TH + 2;
     static constexpr int CW = EW + BS - 1, CH = EH + BS - 1;
@@ -365,13 +198,13 @@ __device__ __forceinline__ void sobel_d2(f2 a0, f2 b0, f2 c0, f2 a1, f2 c1, f2 a
 }
 
 template <int BS>
-__global__ __launch_bounds__(256) void k_eig_nms2(const uint8_t* __restrict__ img, int w, int h, int pitch, float k0,
+__global__ __launch_bounds__(256) void k_eig_nms(const uint8_t* __restrict__ img, int w, int h, int pitch, float k0,
                                                   float k1, const uint8_t* __restrict__ mask, int mask_pitch,
                                                   unsigned* __restrict__ max_key,
                                                   unsigned long long* __restrict__ raw, int* __restrict__ blk_count,
                                                   float* __restrict__ eig_out)
 {
-    using C = EigCfg2<BS>;
+    using C = EigCfg<BS>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* U = reinterpret_cast<uint32_t*>(smem);
     float* D = reinterpret_cast<float*>(smem + C::U_BYTES);        // [2][CH][CWP]: dx, dy
@@ -467,26 +300,17 @@ __global__ __launch_bounds__(256) void k_eig_nms2(const uint8_t* __restrict__ im
 #pragma unroll
             for (int i = 0; i < C::RX + BS - 1; i++) v[i] = (double)__fmul_rn(a[i], b[i]);
             double* o = hs + cy * C::EW + g * C::RX;
+            double r[C::RX];
+            window_sums<C::RX, BS>(v, r);
 #pragma unroll
-            for (int i = 0; i < C::RX; i++) {
-                double s = 0;
-#pragma unroll
-                for (int k = 0; k < BS; k++) s += v[i + k];
-                o[i] = s;
-            }
+            for (int i = 0; i < C::RX; i++) o[i] = r[i];
         }
         __syncthreads();
         if (col_task) {
             double v[C::RY + BS - 1];
 #pragma unroll
             for (int i = 0; i < C::RY + BS - 1; i++) v[i] = hs[(cg * C::RY + i) * C::EW + cex];
-#pragma unroll
-            for (int i = 0; i < C::RY; i++) {
-                double s = 0;
-#pragma unroll
-                for (int k = 0; k < BS; k++) s += v[i + k];
-                S[p][i] = s;
-            }
+            window_sums<C::RY, BS>(v, S[p]);
         }
         __syncthreads();   // hs is rewritten by the next plane; after the last one D is dead as well
     }
@@ -981,28 +805,18 @@ void sobel_scale(int block_size, float* k0, float* k1)
 
 template <int BS>
 void launch_fused(hipStream_t s, const Level& img, float k0, float k1, const uint8_t* mask, int mask_pitch,
-                  unsigned* max_key, unsigned long long* raw, int* blk_count, float* eig_out, CandSrc* src,
-                  bool background)
+                  unsigned* max_key, unsigned long long* raw, int* blk_count, float* eig_out, CandSrc* src)
 {
     using C = EigCfg<BS>;
-    using C2 = EigCfg2<BS>;
-    static const char* form_env = getenv("ICELK_EIG_FORM");   // "1" / "2": force one form (A/B measurements)
-    const bool first_form = form_env ? form_env[0] == '1' : background;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eig_nms<BS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             C::LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eig_nms2<BS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            C2::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid((img.w + C::TW - 1) / C::TW, (img.h + C::TH - 1) / C::TH);
-    if (first_form)
-        hipLaunchKernelGGL((k_eig_nms<BS>), grid, dim3(256), C::LDS_BYTES, s, img.ptr, img.w, img.h, img.pitch, k0, k1,
-                           mask, mask_pitch, max_key, raw, blk_count, eig_out);
-    else
-        hipLaunchKernelGGL((k_eig_nms2<BS>), grid, dim3(256), C2::LDS_BYTES, s, img.ptr, img.w, img.h, img.pitch, k0, k1,
-                           mask, mask_pitch, max_key, raw, blk_count, eig_out);
+    hipLaunchKernelGGL((k_eig_nms<BS>), grid, dim3(256), C::LDS_BYTES, s, img.ptr, img.w, img.h, img.pitch, k0, k1, mask,
+                       mask_pitch, max_key, raw, blk_count, eig_out);
     src->keys = raw;
     src->blk_count = blk_count;
     src->nblk = (int)(grid.x * grid.y);
@@ -1070,7 +884,7 @@ void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, bool full)
 
 // Candidate collection (K6+K7) into regions of D.raw (stream order, no host sync).
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
-                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null, bool background)
+                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null)
 {
     unsigned long long* raw = D.raw;
     CandSrc g_src{};
@@ -1078,10 +892,10 @@ void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int bl
         float k0, k1;
         sobel_scale(block_size, &k0, &k1);
         switch (block_size) {
-            case 3: launch_fused<3>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, background); break;
-            case 5: launch_fused<5>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, background); break;
-            case 7: launch_fused<7>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, background); break;
-            default: launch_fused<10>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, background); break;
+            case 3: launch_fused<3>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
+            case 5: launch_fused<5>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
+            case 7: launch_fused<7>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
+            default: launch_fused<10>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
         }
     } else {
         launch_min_eig(s, img, block_size, D.eig, mask, mask_pitch, D.max_key);

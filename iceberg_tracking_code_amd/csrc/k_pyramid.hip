@@ -1,0 +1,247 @@
+// k_pyramid.hip -- the Gaussian pyramid of a frame in ONE launch (up to three pyrDown levels per launch) for gfx950.
+//
+// Replaces the per-level pyrDown launches inside cv2.calcOpticalFlowPyrLK -> buildOpticalFlowPyramid
+// (s1_lucaskanade_tracking.py:323,326; arithmetic restated from OpenCV's pyrDown, SURVEY.md A.2/A.3: separable
+// [1 4 6 4 1], (sum + 128) >> 8, BORDER_REFLECT_101 at every level, dst = ((w+1)/2, (h+1)/2)).
+//
+// Why one launch: level l+1 needs level l complete, so three launches are three dependent passes, and the upper two
+// have too few pixels to fill the chip: each lasts one workgroup's latency (~8 us) whatever its size -- 33 us per
+// 12 MP frame for 19.7 MB of traffic, 7 % of the HBM rate.  Here a workgroup owns a 128x128 tile of level 0 and builds
+// everything above it: the 64x64 tile of level 1, 32x32 of level 2, 16x16 of level 3.  The level-l values a tile needs
+// from its neighbours (2 px each side, doubling downwards: 14 px of level 0) are recomputed rather than exchanged:
+// 35 % more level-0 bytes through L2, no inter-workgroup dependency, every HBM byte of level 0 read once.
+//   stage 1  the level-0 region (149 rows x 156 B) into LDS as aligned dwords, all loads of a thread in flight at once
+//   stage 2  level 1 region (73 x 75) from LDS into LDS; the owned 64x64 block goes out as whole dwords
+//   stage 3  level 2 region (35 x 35) likewise, stage 4  level 3 (16 x 16)
+// A task = one output column x a run of CH output rows: the horizontal 5-tap sum of a source row is ONE
+// v_dot4_u32_u8 (weights 1 4 6 4 on four bytes cut out of two LDS dwords by v_alignbyte) + the fifth byte, and is
+// shared by the 2-3 output rows that use the row: ~13 vector instructions per output pixel.
+// Borders: a tile at the frame edge completes every region before it is read -- the two positions outside each image
+// edge (all that the taps of an in-image output can reach) are copied, inside LDS, from their mirror positions
+// (BORDER_REFLECT_101 of that level's own image).  The 5x5 arithmetic itself never looks at a coordinate: one code
+// path for every tile; outputs outside the image are computed on whatever the region holds and never stored.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "icelk_internal.h"
+
+namespace icelk {
+
+namespace {
+
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    // every coordinate a tile asks for lies within [-20, n + 156): one reflection does it unless the level is smaller
+    // than that (n is the same for every lane: a scalar branch); the loop handles any p and n
+    if (n >= 256) {
+        p = p < 0 ? -p : p;
+        return p >= n ? 2 * n - 2 - p : p;
+    }
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+constexpr int T0 = 128;                        // owned level-0 tile
+// region origins relative to the tile origin of that level, and region sizes (columns are padded to dword multiples so
+// that the owned block starts on a dword)
+constexpr int L0_OX = -20, L0_OY = -14, L0_W = 156, L0_H = 149;   // needs [-18,134] x [-14,134]
+constexpr int L1_OX = -8, L1_OY = -6, L1_W = 76, L1_H = 73;       // needs [-6,66]: columns 2.. of the region
+constexpr int L2_OX = -4, L2_OY = -2, L2_W = 40, L2_H = 35;       // needs [-2,32]: columns 2.. of the region
+constexpr int L3_W = 16, L3_H = 16;
+constexpr int L0_BYTES = L0_W * L0_H, L1_BYTES = L1_W * L1_H, L2_BYTES = L2_W * L2_H, L3_BYTES = L3_W * L3_H;
+constexpr int LDS_BYTES = ((L0_BYTES + 15) & ~15) + ((L1_BYTES + 15) & ~15) + ((L2_BYTES + 15) & ~15) + L3_BYTES;
+
+struct LevelIO {
+    uint8_t* ptr;
+    int w, h, pitch;
+};
+
+// One task of a level: output column `ox` (region index), output rows oy0 .. oy0+CH-1 (region indices) of a
+// destination region, from a source region in LDS.
+//   src col of tap k = 2*ox + scol + k,  src row of tap k of output row oy = 2*oy + srow + k   (region indices)
+// interior: every tap is inside the source region as it stands.  Otherwise the taps are reflected on the GLOBAL
+// coordinates of the source level (gsx0, gsy0 = global coordinates of source region index 0).
+template <int CH>
+__device__ __forceinline__ void pyr_task(const uint8_t* __restrict__ src, int spitch, int scol, uint8_t* __restrict__ dst,
+                                         int dpitch, int ox, int oy0)
+{
+    constexpr int NR = 2 * CH + 3;
+    int hs[NR];
+    const int c0 = 2 * ox + scol;
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        // bytes c0 .. c0+4 of the row out of the two dwords that hold them (c0 is even: byte offset 0 or 2): the four
+        // weighted ones cut out by v_alignbyte, summed by one v_dot4_u32_u8 with the fifth as its addend
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(src + (2 * oy0 + i) * spitch + (c0 & ~3));
+        const uint32_t d0 = p[0], d1 = p[1];
+        const uint32_t four = __builtin_amdgcn_alignbyte(d1, d0, c0 & 3);
+        const uint32_t fifth = (c0 & 2) ? ((d1 >> 16) & 255u) : (d1 & 255u);
+        hs[i] = (int)__builtin_amdgcn_udot4(four, 0x04060401u, fifth, false);
+    }
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+        const int v = hs[2 * j] + hs[2 * j + 4] + 4 * (hs[2 * j + 1] + hs[2 * j + 3]) + 6 * hs[2 * j + 2];
+        dst[(oy0 + j) * dpitch + ox] = (uint8_t)((v + 128) >> 8);
+    }
+}
+
+// One level of the tile: NCOL x ROWS outputs of the destination region (columns from column FIRST_COL of the region),
+// runs of CH rows per task; the ROWS % CH rows left over are tasks of their own (a run of CH with one live row would
+// cost as much as a full one).  Region index (ox, oy) <-> source region: column 2*ox + scol, row 2*oy.
+template <int CH, int NCOL, int ROWS, int FIRST_COL>
+__device__ __forceinline__ void pyr_level(const uint8_t* __restrict__ src, int spitch, int scol, uint8_t* __restrict__ dst,
+                                          int dpitch, int tid)
+{
+    constexpr int NFULL = ROWS / CH, REM = ROWS - NFULL * CH;
+    for (int t = tid; t < NCOL * NFULL; t += 256) {
+        const int ch = t / NCOL;
+        pyr_task<CH>(src, spitch, scol, dst, dpitch, FIRST_COL + (t - ch * NCOL), ch * CH);
+    }
+    if constexpr (REM > 0) {
+        // the leftover rows: threads from the far end of the workgroup, so that they fall into the partly filled last
+        // round of the loop above rather than into a round of their own
+        for (int t = 255 - tid; t < NCOL; t += 256) pyr_task<REM>(src, spitch, scol, dst, dpitch, FIRST_COL + t, NFULL * CH);
+    }
+}
+
+// A tile at the frame edge: the two positions next to each image edge (all a 5-tap filter centred inside the image can
+// reach) take the value of their mirror positions (BORDER_REFLECT_101), which the same region holds: first the four
+// columns -2, -1, w, w+1 over every row, then -- behind a barrier, so that the corners come out right -- the four rows
+// -2, -1, h, h+1 over every column.  (gx0, gy0) = global coordinates of region (0, 0).  A few hundred byte copies.
+__device__ __forceinline__ void fill_edges(uint8_t* __restrict__ reg, int pitch, int cols, int rows, int gx0, int gy0, int w,
+                                           int h, int tid)
+{
+    for (int i = tid; i < 4 * rows; i += 256) {
+        const int k = i & 3, r = i >> 2;
+        const int gx = k < 2 ? k - 2 : w + (k - 2);
+        const int c = gx - gx0, sc = reflect101(gx, w) - gx0;
+        if ((unsigned)c < (unsigned)cols && (unsigned)sc < (unsigned)cols) reg[r * pitch + c] = reg[r * pitch + sc];
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * cols; i += 256) {
+        const int k = i & 3, c = i >> 2;
+        const int gy = k < 2 ? k - 2 : h + (k - 2);
+        const int r = gy - gy0, sr = reflect101(gy, h) - gy0;
+        if ((unsigned)r < (unsigned)rows && (unsigned)sr < (unsigned)rows) reg[r * pitch + c] = reg[sr * pitch + c];
+    }
+    __syncthreads();
+}
+
+// the owned block of a region goes to global memory as dwords: rows [ry, ry+rows) x byte columns [rx, rx + 4*dwords)
+__device__ __forceinline__ void copy_out(const uint8_t* __restrict__ reg, int rpitch, int rx, int ry, int rows, int dwords,
+                                         const LevelIO& L, int gx0, int gy0, int tid)
+{
+    for (int i = tid; i < rows * dwords; i += 256) {
+        const int r = i / dwords, c = i - r * dwords;
+        const int gy = gy0 + r, gx = gx0 + 4 * c;
+        if (gy < L.h && gx < L.w)   // a last dword may run into the row padding (pitch is a multiple of 64): harmless
+            *reinterpret_cast<uint32_t*>(L.ptr + (size_t)gy * L.pitch + gx) =
+                *reinterpret_cast<const uint32_t*>(reg + (ry + r) * rpitch + rx + 4 * c);
+    }
+}
+
+template <int NL>
+__global__ __launch_bounds__(256) void k_pyramid(LevelIO S, LevelIO D1, LevelIO D2, LevelIO D3, unsigned long long* stamps)
+{
+#define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[8 * (blockIdx.y * gridDim.x + blockIdx.x) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    STAMP(0);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+    uint8_t* R0 = lds;
+    uint8_t* R1 = R0 + ((L0_BYTES + 15) & ~15);
+    uint8_t* R2 = R1 + ((L1_BYTES + 15) & ~15);
+    uint8_t* R3 = R2 + ((L2_BYTES + 15) & ~15);
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * T0, y0 = blockIdx.y * T0;          // level-0 tile origin
+    const int x1 = x0 / 2, y1 = y0 / 2, x2 = x0 / 4, y2 = y0 / 4, x3 = x0 / 8, y3 = y0 / 8;
+    // every tap of every level inside its region as it stands <=> the level-0 region lies inside the image (the
+    // regions of the upper levels are its images)
+    const bool interior = x0 + L0_OX >= 0 && y0 + L0_OY >= 0 && x0 + L0_OX + L0_W <= S.w && y0 + L0_OY + L0_H <= S.h;
+
+    // ---- stage 1: level-0 region into LDS ---------------------------------------------------------------------------
+    // Aligned dwords; a dword is fetched iff its first column and its row are inside the image -- the region origin is
+    // 4-aligned, so no dword straddles the LEFT edge, and one that straddles the right edge reads into the row padding
+    // (pitch is a multiple of 64), bytes the edge fill below overwrites or nothing ever looks at.  No byte path, no
+    // branch: every load of the thread is in flight before the first LDS write waits for one.
+    {
+        constexpr int NDW = L0_W / 4, N = (NDW * L0_H + 255) / 256;
+        uint32_t v[N];
+        const int gx0 = x0 + L0_OX, gy0 = y0 + L0_OY;
+#pragma unroll
+        for (int m = 0; m < N; m++) {
+            const int i = tid + 256 * m;
+            const int r = i / NDW, c = i - r * NDW;
+            const int gy = gy0 + r, gx = gx0 + 4 * c;
+            const bool ok = i < NDW * L0_H && (unsigned)gy < (unsigned)S.h && (unsigned)gx < (unsigned)S.w;
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(S.ptr + (size_t)(ok ? gy : 0) * S.pitch + (ok ? gx : 0));
+            v[m] = ok ? *p : 0u;
+        }
+#pragma unroll
+        for (int m = 0; m < N; m++) {
+            const int i = tid + 256 * m;
+            if (i < NDW * L0_H) reinterpret_cast<uint32_t*>(R0)[i] = v[m];
+        }
+    }
+    __syncthreads();
+    if (!interior) fill_edges(R0, L0_W, L0_W, L0_H, x0 + L0_OX, y0 + L0_OY, S.w, S.h, tid);
+    STAMP(1);
+
+    // ---- stages 2-4: level 1 (region columns 2 .. 74, rows 0 .. 72), level 2 (columns 2 .. 36, rows 0 .. 34), level 3 ----
+    // region index (ox, oy) of a level <-> source region: column 2*ox + scol, row 2*oy, with scol = +2, -2, +2
+    pyr_level<8, L1_W - 3, L1_H, 2>(R0, L0_W, 2, R1, L1_W, tid);
+    __syncthreads();
+    STAMP(2);
+    copy_out(R1, L1_W, -L1_OX, -L1_OY, T0 / 2, T0 / 8, D1, x1, y1, tid);
+    STAMP(3);
+    if (NL == 1) return;
+    if (!interior) fill_edges(R1, L1_W, L1_W, L1_H, x1 + L1_OX, y1 + L1_OY, D1.w, D1.h, tid);
+    pyr_level<8, 35, L2_H, 2>(R1, L1_W, -2, R2, L2_W, tid);
+    __syncthreads();
+    STAMP(4);
+    copy_out(R2, L2_W, -L2_OX, -L2_OY, T0 / 4, T0 / 16, D2, x2, y2, tid);
+    if (NL == 2) return;
+    if (!interior) fill_edges(R2, L2_W, L2_W, L2_H, x2 + L2_OX, y2 + L2_OY, D2.w, D2.h, tid);
+    pyr_level<2, L3_W, L3_H, 0>(R2, L2_W, 2, R3, L3_W, tid);
+    __syncthreads();
+    copy_out(R3, L3_W, 0, 0, T0 / 8, T0 / 32, D3, x3, y3, tid);
+    STAMP(5);
+}
+
+LevelIO io_of(const Level& L)
+{
+    LevelIO o;
+    o.ptr = L.ptr;
+    o.w = L.w;
+    o.h = L.h;
+    o.pitch = L.pitch;
+    return o;
+}
+
+}  // namespace
+
+// Builds lv[first+1 .. first+n] (n = 1..3) from lv[first] in one launch.
+void launch_pyramid_fused(hipStream_t s, const Level* lv, int first, int n)
+{
+    const Level& S = lv[first];
+    dim3 grid((S.w + T0 - 1) / T0, (S.h + T0 - 1) / T0);
+    const LevelIO src = io_of(S), d1 = io_of(lv[first + 1]);
+    const LevelIO d2 = n >= 2 ? io_of(lv[first + 2]) : d1, d3 = n >= 3 ? io_of(lv[first + 3]) : d1;
+    // diagnostics: ICELK_PYR_STAMPS=<file> records s_memtime at the stage boundaries of every workgroup of each launch
+    static unsigned long long* d_st = nullptr;
+    static const char* st_path = getenv("ICELK_PYR_STAMPS");
+    const size_t nst = 8 * (size_t)grid.x * grid.y;
+    if (st_path && !d_st) hipMalloc(reinterpret_cast<void**>(&d_st), 8 * 8 * 65536);
+    if (n == 1) hipLaunchKernelGGL(k_pyramid<1>, grid, dim3(256), 0, s, src, d1, d2, d3, d_st);
+    else if (n == 2) hipLaunchKernelGGL(k_pyramid<2>, grid, dim3(256), 0, s, src, d1, d2, d3, d_st);
+    else hipLaunchKernelGGL(k_pyramid<3>, grid, dim3(256), 0, s, src, d1, d2, d3, d_st);
+    if (d_st && nst <= 8 * 65536) {
+        std::vector<unsigned long long> hst(nst);
+        hipStreamSynchronize(s);
+        hipMemcpy(hst.data(), d_st, nst * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(st_path, "wb")) { fwrite(hst.data(), 8, nst, f); fclose(f); }
+    }
+}
+
+}  // namespace icelk

@@ -22,8 +22,11 @@ def test_gray(ctx, orc, w, h, variant):
     assert np.array_equal(got, orc.bgr2gray(img, variant))
 
 
-@pytest.mark.parametrize("w,h", [(640, 480), (641, 479), (333, 257), (64, 48), (23, 31), (100, 8)])
+@pytest.mark.parametrize("w,h", [(640, 480), (641, 479), (333, 257), (64, 48), (23, 31), (100, 8), (1023, 767), (129, 257),
+                                 (128, 128), (127, 385), (1000, 3), (1, 70)])
 def test_pyramid(ctx, orc, synth, w, h):
+    """All levels, bit for bit: the one-launch kernel (three levels per launch, tiles with recomputed halos, reflection
+    at every level's own border) -- sizes around the 128-px tile, odd sizes, levels narrower than a halo."""
     rng = np.random.RandomState(w + 13 * h)
     img = rng.randint(0, 256, size=(h, w)).astype(np.uint8)
     ctx.upload_gray(0, img)
@@ -34,6 +37,24 @@ def test_pyramid(ctx, orc, synth, w, h):
         got = ctx.download_level(0, l)
         assert got.shape == r.shape
         assert np.array_equal(got, r), "level %d differs" % l
+
+
+def test_pyramid_kernels_agree(synth, monkeypatch):
+    """The per-level kernel (ICELK_PYR_PER_LEVEL=1) and the fused one are two statements of the same arithmetic."""
+    from iceberg_tracking_code_amd import Context
+    img = synth.frame(1000, 700, 77, -31, 5)
+    out = []
+    for per_level in (False, True):
+        if per_level:
+            monkeypatch.setenv("ICELK_PYR_PER_LEVEL", "1")
+        c = Context(1000, 700, n_slots=1, max_pts=64)
+        c.upload_gray(0, img)
+        top = c.build_pyramid(0, (9, 9), 5)
+        out.append([c.download_level(0, l) for l in range(top + 1)])
+        c.close()
+    assert len(out[0]) == len(out[1]) == 6
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
 
 
 def test_pyramid_stop_rule(ctx, orc, synth):
