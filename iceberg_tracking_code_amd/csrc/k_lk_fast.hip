@@ -224,7 +224,7 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
 }
 
 template <int WW, int WH, bool FB>
-__global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : 2)) void k_lk_fast(Pyramid PI, Pyramid PJ, LKBuffers B, int n, LKParams P)
+__global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : (Cfg<WW, WH>::TPL == 2 ? 3 : 2))) void k_lk_fast(Pyramid PI, Pyramid PJ, LKBuffers B, int n, LKParams P)
 {
     using C = Cfg<WW, WH>;
     __shared__ uint32_t lds[C::LDS_DW];
