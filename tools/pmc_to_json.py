@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""profiles/pmc_<config>.json from a pmc_summary.txt (tools/collect_profiles.sh): the per-launch counters of the tracker
+kernel that bench.py puts beside its live timings.   Usage: tools/pmc_to_json.py <pmc_summary.txt> <config> <source text>"""
+import json, re, sys
+
+summary, cfg, source = sys.argv[1], sys.argv[2], sys.argv[3]
+blocks, cur = {}, None
+for line in open(summary):
+    if not line.startswith(" "):
+        cur = line.strip()
+        blocks[cur] = {}
+    else:
+        m = re.match(r"\s+(\S+)\s+n=(\d+)\s+mean=(\S+)", line)
+        if m:
+            blocks[cur][m.group(1)] = float(m.group(3))
+lk = next(v for k, v in blocks.items() if k.startswith("k_lk_fast") and "true" in k)
+kib = 1024.0
+out = {
+    "source": source,
+    "kernel": next(k for k in blocks if k.startswith("k_lk_fast") and "true" in k),
+    # FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE shows half the
+    # bytes of WIDE (16 B/lane) coalesced reads; this kernel gathers single dwords, an access width the guide calls
+    # uncalibrated -- the value is given as counted, and doubled as the upper bound
+    "lk_fb_fetch_bytes_per_launch": lk.get("FETCH_SIZE", 0) * kib,
+    "lk_fb_write_bytes_per_launch": lk.get("WRITE_SIZE", 0) * kib,
+    "lk_fb_bytes_per_launch": (lk.get("FETCH_SIZE", 0) + lk.get("WRITE_SIZE", 0)) * kib,
+    "lk_fb_bytes_per_launch_fetch_doubled": (2 * lk.get("FETCH_SIZE", 0) + lk.get("WRITE_SIZE", 0)) * kib,
+    "lk_fb_valu_insts_per_launch": lk.get("SQ_INSTS_VALU"),
+    "lk_fb_salu_insts_per_launch": lk.get("SQ_INSTS_SALU"),
+    "lk_fb_lds_insts_per_launch": lk.get("SQ_INSTS_LDS"),
+    "lk_fb_waves_per_launch": lk.get("SQ_WAVES"),
+    "lk_fb_lds_bank_conflict_ratio": (lk["SQ_LDS_BANK_CONFLICT"] / lk["SQ_LDS_IDX_ACTIVE"]) if lk.get("SQ_LDS_IDX_ACTIVE") else None,
+    # share of a wave's lifetime: issuing VALU, stalled at issue, parked at a waitcnt / barrier (quad-cycle counters)
+    "lk_fb_wave_time_shares": {k: lk[c] / lk["SQ_WAVE_CYCLES"] for k, c in (("valu_active", "SQ_ACTIVE_INST_VALU"),
+                               ("issue_stall", "SQ_WAIT_INST_ANY"), ("parked", "SQ_WAIT_ANY")) if lk.get(c) and lk.get("SQ_WAVE_CYCLES")},
+}
+if lk.get("GRBM_GUI_ACTIVE") and lk.get("SQ_ACTIVE_INST_VALU"):
+    # gfx9 VALUBusy: quad-cycles of VALU issue summed over the SIMDs x 4 / (1024 SIMDs x GPU-active cycles); GRBM_GUI_ACTIVE
+    # is the sum over the 8 XCDs
+    out["lk_fb_valu_busy_pct"] = 100.0 * lk["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * lk["GRBM_GUI_ACTIVE"] / 8.0)
+res = json.load(open("profiles/r02_lk_resources.json"))
+out.update(lk_fb_vgprs=res["k_lk_fast<21,21,true>"]["vgprs"], lk_fb_waves_per_simd=res["k_lk_fast<21,21,true>"]["waves_per_simd"],
+           lk_fb_sgpr_spills=res["k_lk_fast<21,21,true>"]["sgpr_spills"])
+# cycles per wave64 instruction per SIMD at >= 4 waves per SIMD, by instruction class (profiles/r02_valu_rate.txt)
+out["valu_cycles_per_inst"] = {"add_shift_mov_fma_f32_class": 3.0, "dot2_perm_mad_pk_cvt_f64_class": 4.7}
+out["valu_cycles_source"] = ("tools/ubench/valu_rate.hip -> profiles/r02_valu_rate.txt (16 instructions per loop body by "
+                             "construction, checked in the disassembly; 1024 SIMDs x 2.4 GHz)")
+json.dump(out, open("profiles/pmc_%s.json" % cfg, "w"), indent=1)
+print(json.dumps(out, indent=1))
