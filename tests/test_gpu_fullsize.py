@@ -142,3 +142,116 @@ def test_segment_tracker_c2_counts(synth):
             flow = synth.true_flow(sh[first + v], sh[first + v + 1])
             assert np.median(np.abs((tracks[:, v + 1] - tracks[:, v]) - flow)) < 0.03
         assert np.all(quality < 1.0)
+
+
+def test_c3_sixty_four_pairs_streamed_from_pinned_memory(synth, orc):
+    """BASELINE.json configs[2] at its real size: 65 consecutive 4000x3000 frames cross PCIe from pinned host memory
+    (hipMemcpyAsync, three uploads in flight, six slots) while the segments are tracked.  Checked through properties that
+    do not need a CPU run at this size -- every segment comes back, same tracks as the loop over HBM-resident frames (bit
+    for bit), recovered flow = the known motion -- plus the oracle on a crop of one pair."""
+    import ctypes as C
+    from iceberg_tracking_code_amd import Context, SegmentTracker
+    n, T = 65, 2
+    fp = dict(maxCorners=10000, qualityLevel=0.007, minDistance=10, blockSize=10)
+    sh = synth.shifts(n, seed=77)
+    af = synth.affines(n, seed=77)
+    res = Context(W, H, n_slots=n, max_pts=1 << 14)
+    for i in range(n):
+        res.synth_frame(i, W, H, int(sh[i, 0]), int(sh[i, 1]), 77, affine=af[i])
+    res.sync()
+    # reference run: frames resident, everything done at its own frame (no look-ahead)
+    ref = SegmentTracker(W, H, T, fp, LK_C2, ctx=res, lookahead=False)
+    want = [s for s in (ref.push_slot(i, wait=True) for i in range(n)) if s is not None]
+    assert len(want) == (n - 1) // T
+    # the same frames parked in pinned host memory
+    pinned = []
+    for i in range(n):
+        img = np.ascontiguousarray(res.download_level(i, 0))
+        p = res.host_alloc(W * H)
+        C.memmove(p, img.ctypes.data, W * H)
+        pinned.append(p)
+        if i == 10:
+            crop0 = img[1000:1400, 1500:2100].copy()
+        if i == 11:
+            crop1 = img[1000:1400, 1500:2100].copy()
+    res.close()
+    trk = SegmentTracker(W, H, T, fp, LK_C2, max_pts=1 << 14, n_slots=6)
+    got = []
+    for i in range(3):
+        trk.prefetch_pinned(pinned[i], W)
+    for i in range(n):
+        if i + 3 < n:
+            trk.prefetch_pinned(pinned[i + 3], W)
+        s = trk.push_prefetched(wait=True)
+        if s is not None:
+            got.append(s)
+    trk.ctx.sync()
+    for p in pinned:
+        trk.ctx.host_free(p)
+    trk.close()
+    assert len(got) == len(want) == 32
+    for (fa, ta, qa), (fb, tb, qb) in zip(want, got):
+        assert fa == fb and ta.shape[1:] == (T + 1, 2) and len(ta) > 8000
+        assert np.array_equal(ta, tb) and np.array_equal(qa, qb)
+    # the tracks follow the motion the frames were generated with (translation + <= 0.5 % deformation: compare with the
+    # exact displacement of the texture point under each track's first vertex)
+    first, tracks, _ = got[5]
+    one = 1 << 20
+
+    def tex(i, xy):   # texture coordinate sampled at pixel xy of frame i
+        x, y = xy[:, 0].astype(np.float64), xy[:, 1].astype(np.float64)
+        return np.stack([x + sh[i, 0] / 256.0 + (af[i, 0] * x + af[i, 1] * y) / one,
+                         y + sh[i, 1] / 256.0 + (af[i, 2] * x + af[i, 3] * y) / one], 1)
+    d = np.abs(tex(first, tracks[:, 0]) - tex(first + 1, tracks[:, 1]))   # the same texture point must be under both
+    assert np.median(d) < 0.05 and np.percentile(d, 95) < 0.25
+    # oracle on a crop of one pair (frames 10 -> 11), features of the crop detected by the oracle itself
+    pts = orc.good_features(crop0, 500, 0.007, 10, None, 10).reshape(-1, 2)
+    c = Context(600, 400, n_slots=2, max_pts=4096)
+    c.upload_gray(0, crop0)
+    c.upload_gray(1, crop1)
+    g = c.track_fb(0, 1, pts, **LK_C2)
+    c.close()
+    r = orc.track_fb(crop0, crop1, pts, **LK_C2)
+    for k in ("p1", "p0r", "err_fwd", "err_bwd", "dist", "st_fwd", "st_bwd", "valid"):
+        assert np.array_equal(g[k].view(np.uint8), r[k].view(np.uint8)), k
+
+
+def test_segment_archive_and_iteration_counts(synth):
+    """icelk_seg_archive (the device-side read-out of a finished segment that a sharded run gathers over RCCL) gives the
+    rows icelk_seg_read gives; icelk_prof_iterations reports one (forward, backward) count per live track."""
+    import ctypes as C
+    from iceberg_tracking_code_amd import Context
+    hip = C.CDLL("libamdhip64.so")
+    w, h = 1024, 768
+    c = Context(w, h, n_slots=3, max_pts=4096)
+    sh = synth.shifts(3, seed=5)
+    for i in range(3):
+        c.synth_frame(i, w, h, int(sh[i, 0]), int(sh[i, 1]), 5)
+    n0 = c.seg_detect(0, 2000, 0.007, 10, False, 10)
+    c.prof_enable(True)
+    c.seg_track(0, 1, **LK_C2)
+    c.seg_track(1, 2, **LK_C2)
+    itf, itb = c.prof_iterations()
+    c.prof_enable(False)
+    tracks, quality = c.seg_read()
+    assert 1000 < len(tracks) <= n0 and len(itf) == len(itb) and len(tracks) <= len(itf) <= n0
+    assert itf.min() >= 1 and itf.max() <= 4 * 30 and itb.max() <= 4 * 30
+    rows = 2048
+    bufs = [C.c_void_p() for _ in range(3)]
+    for b, nbytes in zip(bufs, (rows * 3 * 2 * 4, rows * 2 * 4, 4)):
+        assert hip.hipMalloc(C.byref(b), C.c_size_t(nbytes)) == 0
+    nv = c.seg_archive(bufs[0].value, bufs[1].value, bufs[2].value, rows)
+    c.sync()
+    cnt = np.zeros(1, np.int32)
+    at = np.zeros((rows, 3, 2), np.float32)
+    aq = np.zeros((rows, 2), np.float32)
+    for host, b in ((at, bufs[0]), (aq, bufs[1]), (cnt, bufs[2])):
+        assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), b, C.c_size_t(host.nbytes), 2) == 0   # device to host
+    assert nv == 3 and cnt[0] == len(tracks)
+    assert np.array_equal(at[:cnt[0]], tracks) and np.array_equal(aq[:cnt[0]], quality)
+    from iceberg_tracking_code_amd._lib import IcelkError
+    with pytest.raises(IcelkError, match="-4"):
+        c.seg_archive(bufs[0].value, bufs[1].value, bufs[2].value, 10)   # fewer rows than the segment started with
+    for b in bufs:
+        hip.hipFree(b)
+    c.close()
