@@ -31,8 +31,14 @@
  *   - err of points whose status is 0 is left at 0 (OpenCV leaves it uninitialised).
  *   - equal corner responses are ordered by higher raster address first (OpenCV >= 3.4).
  *   - the box filter sums each window row left-to-right and then the row sums top-to-bottom,
- *     both in double (OpenCV keeps running double sums; the two agree unless a double
- *     rounding differs, probability ~1e-8 per pixel).
+ *     both in double.  OpenCV keeps running double sums; for 8-bit input every term is a float
+ *     product in [2^-27, 2^-3], so every such sum is EXACT in double and the order cannot matter
+ *     (tests/test_oracle_kat.py::test_box_sums_of_the_covariance_planes_are_exact_in_double).
+ *   - Sobel: separately rounded multiply and add in OpenCV's generic RowFilter / SymmColumnSmall
+ *     operation order (a build without FMA contraction, e.g. 3.1 SSE2); an AVX2-dispatched 4.x
+ *     build fuses them (v_muladd) and can differ in the last ulp of the eigenvalue map.
+ *   - the forward-backward distance is the C library's hypotf, as np.hypot on float32 (s1:330);
+ *     pinned against numpy (test_fb_distance_is_numpy_hypot_on_float32).
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
  */
