@@ -243,6 +243,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="leave out the per-kernel HIP events (and with them the roofline object): shows what they cost")
+    ap.add_argument("--no-pair-launch", action="store_true",
+                    help="A/B: the last pair of a segment is launched on its own instead of with the first pair of the next")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="start a detection only when its frame is pushed (A/B of the cross-step overlap)")
     args = ap.parse_args()
@@ -310,11 +312,11 @@ def main():
         torch.cuda.synchronize()
 
     def run_resident(tracker, order, first, count):
-        """`count` steps over frames that sit in HBM; the slots of the next three frames are known to the tracker."""
+        """`count` steps over frames that sit in HBM; the slots of the next four frames are known to the tracker."""
         n = len(order)
         for i in range(first, first + count):
-            nxt = [order[i + k] if i + k < n else None for k in (1, 2, 3)]
-            tracker.push_slot(order[i], wait=False, next_slot=nxt[0], next2_slot=nxt[1], next3_slot=nxt[2])
+            nxt = [order[i + k] if i + k < n else None for k in (1, 2, 3, 4)]
+            tracker.push_slot(order[i], wait=False, next_slot=nxt[0], next2_slot=nxt[1], next3_slot=nxt[2], next4_slot=nxt[3])
 
     # ---- the timed region -------------------------------------------------------------------------------------------------
     order = list(range(ring)) if linear else ping_pong(ring, K + W)
@@ -324,7 +326,7 @@ def main():
         # the timed tracker begins with a clean handle (no detection in flight, no staged segment)
         warm = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx, lookahead=False)
         run_resident(warm, order[:W], 0, W)
-        tracker = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx, lookahead=not args.no_lookahead)
+        tracker = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx, lookahead=not args.no_lookahead, pair_launch=not args.no_pair_launch)
         if cname == "c4":
             # the rank's finished segments stay on the device: (segments, rows, vertices, 2) float32 + counts, gathered
             # over RCCL after the timed region (icelk_seg_archive: no host round trip per segment)
@@ -333,16 +335,17 @@ def main():
             archive = dict(tracks=torch.zeros((max(n_seg, 1), rows, TRACK_LEN + 1, 2), dtype=torch.float32, device="cuda"),
                            counts=torch.zeros(max(n_seg, 1), dtype=torch.int32, device="cuda"), n=0, rows=rows)
 
-            def on_close(first_frame):
+            def on_close(first_frame, closed):
                 s = archive["n"]
                 if s < archive["tracks"].shape[0]:
-                    ctx.seg_archive(archive["tracks"][s].data_ptr(), 0, archive["counts"][s:s + 1].data_ptr(), archive["rows"])
+                    ctx.seg_archive(archive["tracks"][s].data_ptr(), 0, archive["counts"][s:s + 1].data_ptr(), archive["rows"],
+                                    closed=closed)
                     archive["n"] = s + 1
             tracker.on_close = on_close
         timed_order = order[W:]
         t_first, pushes = 0, K + 1    # the first push of a fresh tracker only detects: K + 1 frames = K frame pairs
     else:
-        tracker = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx, lookahead=not args.no_lookahead)
+        tracker = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx, lookahead=not args.no_lookahead, pair_launch=not args.no_pair_launch)
         run_resident(tracker, order, 0, W)
         timed_order = order
         t_first, pushes = W, K        # steady state: every push tracks one pair
@@ -355,6 +358,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run_resident(tracker, timed_order, t_first, pushes)
+    tracker.flush()    # a last pair held back for a joint launch goes out (and is archived) inside the timed region
     barrier()
     t1 = time.perf_counter()
     ctx.prof_enable(False)
@@ -523,7 +527,14 @@ def main():
         if pcie:
             out["pcie_inclusive"] = pcie
         kern = {}
-        lkp = prof.get("lk_fb")
+        # tracker launches of the timed region: single segment pairs and joint launches of two (icelk_seg_track_defer)
+        lk_kinds = [prof[k] for k in ("lk_fb", "lk_fb_pair") if prof.get(k) and prof[k]["launches"]]
+        lkp = None
+        if lk_kinds:
+            nl = sum(k["launches"] for k in lk_kinds)
+            tot_ms = sum(k["total_ms"] for k in lk_kinds)
+            lkp = {"launches": nl, "total_ms": tot_ms, "avg_us": tot_ms * 1e3 / nl,
+                   "pairs_per_launch": (sum(k["launches"] for k in lk_kinds) + (prof.get("lk_fb_pair") or {"launches": 0})["launches"]) / nl}
         if lkp:
             n_avg = tracked / max(lkp["launches"], 1)
             alg = 2.0 * lk_algorithmic_bytes(w, h, cfg["win"], top, n_avg)   # forward + backward
@@ -532,7 +543,7 @@ def main():
                                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                "algorithmic_bytes_per_launch": alg, "avg_launch_us": lkp["avg_us"],
-                               "features_per_launch": n_avg,
+                               "features_per_launch": n_avg, "frame_pairs_per_launch": lkp["pairs_per_launch"],
                                "note": "LK is VALU-issue-bound (SURVEY.md 8d); HBM fraction reported for completeness, the "
                                        "issue fraction is in valu_issue"}
         pd = prof.get("pyrdown")

@@ -65,6 +65,11 @@ SIGNATURES = {
                                   C.c_double, C.c_double, C.c_float, i32p]),
     "icelk_seg_track_async": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_double, C.c_double, C.c_float]),
+    "icelk_seg_track_defer": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_double, C.c_double, C.c_float]),
+    "icelk_seg_flush": (C.c_int, [handle_p]),
+    "icelk_seg_read_closed": (C.c_int, [handle_p, f32p, f32p, C.c_int, C.c_int, i32p, i32p]),
+    "icelk_seg_archive_closed": (C.c_int, [handle_p, vp, vp, vp, C.c_int, i32p]),
     "icelk_seg_live": (C.c_int, [handle_p, i32p, i64p]),
     "icelk_seg_archive": (C.c_int, [handle_p, vp, vp, vp, C.c_int, i32p]),
     "icelk_project_tracks": (C.c_int, [handle_p, f32p, C.c_int, C.c_int, vp, vp, f64p, f64p, f64p, f64p, f64p, u8p]),

@@ -286,27 +286,41 @@ class Context:
                                                  cnt, eps, minEigThreshold, fb_threshold))
         return None
 
+    def seg_track_defer(self, slot_prev, slot_next, winSize=(21, 21), maxLevel=3, criteria=DEFAULT_CRITERIA,
+                        minEigThreshold=1e-4, fb_threshold=1.0):
+        """The last pair of a segment: nothing is launched, the pair goes out together with the first pair of the next
+        segment (one tracker launch for both) -- see icelk_seg_track_defer in include/icelk.h."""
+        t, cnt, eps = _criteria(criteria)
+        self._ck(self._lib.icelk_seg_track_defer(self._h, slot_prev, slot_next, winSize[0], winSize[1], maxLevel, t,
+                                                 cnt, eps, minEigThreshold, fb_threshold))
+
+    def seg_flush(self):
+        self._ck(self._lib.icelk_seg_flush(self._h))
+
     def seg_live(self):
         n, tot = C.c_int(0), C.c_int64(0)
         self._ck(self._lib.icelk_seg_live(self._h, C.byref(n), C.byref(tot)))
         return n.value, tot.value
 
-    def seg_archive(self, dev_tracks_ptr, dev_quality_ptr, dev_count_ptr, cap_rows):
-        """Gather the current segment's surviving tracks into device memory of the caller (no wait); returns the
-        vertex count the rows have."""
+    def seg_archive(self, dev_tracks_ptr, dev_quality_ptr, dev_count_ptr, cap_rows, closed=False):
+        """Gather the current segment's surviving tracks (`closed`: those of the segment the latest switch closed) into
+        device memory of the caller (no wait); returns the vertex count the rows have."""
         nv = C.c_int(0)
-        self._ck(self._lib.icelk_seg_archive(self._h, C.c_void_p(dev_tracks_ptr), C.c_void_p(dev_quality_ptr or 0),
+        fn = self._lib.icelk_seg_archive_closed if closed else self._lib.icelk_seg_archive
+        self._ck(fn(self._h, C.c_void_p(dev_tracks_ptr), C.c_void_p(dev_quality_ptr or 0),
                                              C.c_void_p(dev_count_ptr), int(cap_rows), C.byref(nv)))
         return nv.value
 
-    def seg_read(self):
-        """(tracks (n, V, 2) f32, trackquality (n, V-1) f32): what np.savez stores at s1:394-395."""
+    def seg_read(self, closed=False):
+        """(tracks (n, V, 2) f32, trackquality (n, V-1) f32): what np.savez stores at s1:394-395.  `closed`: of the
+        segment the latest switch closed instead of the current one."""
         n, nv = C.c_int(0), C.c_int(0)
-        self._ck(self._lib.icelk_seg_read(self._h, None, None, 0, 0, C.byref(n), C.byref(nv)))
+        fn = self._lib.icelk_seg_read_closed if closed else self._lib.icelk_seg_read
+        self._ck(fn(self._h, None, None, 0, 0, C.byref(n), C.byref(nv)))
         tracks = np.zeros((n.value, nv.value, 2), np.float32)
         quality = np.zeros((n.value, max(nv.value - 1, 0)), np.float32)
         if n.value:
-            self._ck(self._lib.icelk_seg_read(self._h, _f32(tracks), _f32(quality), n.value, nv.value, C.byref(n),
+            self._ck(fn(self._h, _f32(tracks), _f32(quality), n.value, nv.value, C.byref(n),
                                               C.byref(nv)))
         return tracks, quality
 

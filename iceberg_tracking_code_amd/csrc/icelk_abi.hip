@@ -11,11 +11,13 @@
 
 namespace icelk {
 
+constexpr int kSegSets = 4;
+constexpr int kLaunchEvents = 32;
 constexpr int kMaxVert = 17;  // vertices per track kept on the device (track_len <= 16; reference uses 2)
 
 static const char* kKernelNames[K_COUNT_] = {
     "bgr2gray", "pyrdown", "lk", "lk_fb", "corner_candidates", "min_distance", "sort_emit",
-    "project_tracks", "synth",
+    "project_tracks", "synth", "lk_fb_pair",
 };
 
 struct DetectJob {
@@ -34,6 +36,18 @@ struct Ctx {
     // Detection (corner candidates, min-distance, sort) runs on its own stream: it only needs the frame,
     // not the tracker's results, so it overlaps the LK launch of the same frame (s1:323-326 vs s1:437).
     hipStream_t det_stream = nullptr;
+    // The tail of a detection -- sort of the accepted corners, the corner list, the new segment's initialisation -- runs
+    // on a stream of its own: the detection stream is a serial chain of ~10 short kernels per detection that takes most
+    // of a tracker launch to get through beside that launch, and with the tail (~10 more) behind it on the same stream
+    // the chain of the NEXT detection could not start before the tail was through.  The accepted keys the tail sorts
+    // are double buffered (acc_buf) so that the next min-distance stage may write while the tail still reads.
+    // ICELK_NO_TAIL_STREAM=1 keeps the tail on the detection stream (A/B).
+    hipStream_t tail_stream = nullptr;
+    hipStream_t corners_stream = nullptr;   // where d_corners was produced (tail_stream or det_stream)
+    unsigned long long* acc_buf[2] = {nullptr, nullptr};
+    int acc_idx = 0;                        // D.acc == acc_buf[acc_idx]
+    hipEvent_t acc_read[2] = {nullptr, nullptr};   // the tail that sorted acc_buf[i] has read it
+    bool use_tail_stream = true;
     hipEvent_t det_done = nullptr;      // corners of the latest detection are in d_corners
     hipEvent_t corners_free = nullptr;  // the compute stream has consumed d_corners
     std::vector<Slot> slots;
@@ -84,9 +98,24 @@ struct Ctx {
         int* order_border = nullptr;   // 1 int: leading entries of `order` that are border features
         float* tracks = nullptr;    // [track][kMaxVert][2]
         float* quality = nullptr;   // [track][kMaxVert-1]
-        hipEvent_t used = nullptr;  // last launch on the compute stream that touches this set
-    } sb[2];
+        // last launch on the compute stream that touches this set: own event or a shared launch event (see Slot::used)
+        hipEvent_t used = nullptr, used_own = nullptr;
+        int vert = 0, upper = 0;    // vertices so far, tracks of the segment (= corners detected)
+    } sb[kSegSets];
+    // Four sets rotate: the current segment, the one staged for the next switch (sb_cur + 1), the one closed by the
+    // latest switch (sb_cur - 1), whose last pair may still be waiting (icelk_seg_track_defer) and whose tracks stay
+    // readable (icelk_seg_archive_closed) until the switch after -- and the one before that, which a tracker launch
+    // may still be working on when the host, a launch ahead of the device, stages the next segment.
+    hipEvent_t launch_ev[kLaunchEvents] = {nullptr};   // one per tracker launch, round robin
+    int launch_seq = 0;
     int sb_cur = 0;
+    bool closed_valid = false;
+    struct Deferred {
+        bool pending = false;
+        int set = 0, slot_prev = 0, slot_next = 0;
+        LKJob job{};
+        LKParams P{};
+    } defer;
     hipEvent_t seg_ready = nullptr;   // the current set has been initialised (detection stream)
     bool seg_ready_pending = false;   // ... and the compute stream has not been told to wait for it yet
     bool use_order = true;                 // ICELK_NO_ORDER=1 launches in detector order (A/B measurements)
@@ -95,6 +124,9 @@ struct Ctx {
     int border_px = (10 + 6 + 2) << 2;
     bool border_first = true;
     bool pyr_per_level = false;            // ICELK_PYR_PER_LEVEL=1: one pyrDown launch per level (A/B, second statement)
+    // pyramids built ahead (copy stream, beside a tracker launch) use one-wave workgroups, which fit into the slot of a
+    // single retiring tracker wave (k_pyramid.hip); ICELK_PYR_AHEAD_WIDE=1 keeps the 256-thread geometry there too (A/B)
+    bool pyr_ahead_one_wave = true;
     int fb_dist_form = ICELK_FB_HYPOT;     // icelk_set_fb_distance
     int lk_kernel_flags = 0;               // icelk_set_lk_kernel: ICELK_FLAG_GENERIC_KERNEL / _ONE_PER_WAVE or 0
     // diagnostics: ICELK_LK_STAMPS=<file> records entry / exit time and placement of every workgroup of the LAST
@@ -111,7 +143,6 @@ struct Ctx {
     double* d_proj = nullptr;
     uint8_t* d_keep = nullptr;
     size_t proj_cap = 0;
-    int seg_vert = 0, seg_upper = 0;   // vertices so far, tracks of the segment (= corners detected)
     bool seg_active = false;
     bool seg_staged = false;   // the OTHER set holds a new segment waiting for icelk_seg_switch
     int staged_n = 0;
@@ -258,9 +289,24 @@ static int wait_slot(Ctx* c, int slot)
 
 static int mark_used(Ctx* c, int slot)
 {
-    HIPCHK(c, hipEventRecord(c->slots[slot].used, c->stream));
+    Slot& s = c->slots[slot];
+    HIPCHK(c, hipEventRecord(s.used_own, c->stream));
+    s.used = s.used_own;
     return ICELK_OK;
 }
+
+// An event wait costs a barrier packet on the waiting queue, processed one after the other between its kernels: none
+// when the event has completed already (also: was never recorded)
+static int wait_event(Ctx* c, hipStream_t s, hipEvent_t e)
+{
+    if (hipEventQuery(e) == hipSuccess) return ICELK_OK;
+    (void)hipGetLastError();   // hipErrorNotReady is the expected answer
+    HIPCHK(c, hipStreamWaitEvent(s, e, 0));
+    return ICELK_OK;
+}
+
+static int flush_deferred(Ctx* c);
+static int flush_deferred_slot(Ctx* c, int slot);
 
 static int begin_frame(Ctx* c, int slot, int w, int h)
 {
@@ -268,6 +314,8 @@ static int begin_frame(Ctx* c, int slot, int w, int h)
     if (rc) return rc;
     if (w <= 0 || h <= 0) FAIL(c, ICELK_EARG, "empty image");
     if (w > c->max_w || h > c->max_h) FAIL(c, ICELK_ECAP, "frame larger than max_w x max_h of icelk_create");
+    rc = flush_deferred_slot(c, slot);
+    if (rc) return rc;
     Slot& s = c->slots[slot];
     // a detector launch on another stream may still read the frame this slot holds (compute-stream ingest paths
     // write level 0 right after this call; the copy-stream path waits for the same event itself)
@@ -291,7 +339,7 @@ static int build_levels(Ctx* c, Slot& s, int top_level, hipStream_t st)
         {
             ProfScope p(c, K_PYRDOWN, st);
             if (per_level) launch_pyrdown(st, s.lv[l - 1], s.lv[l]);
-            else launch_pyramid_fused(st, s.lv, l - 1, n);
+            else launch_pyramid_fused(st, s.lv, l - 1, n, c->pyr_ahead_one_wave && st == c->copy_stream);
         }
         int rc = check_launch(c, "pyramid");
         if (rc) return rc;
@@ -373,6 +421,20 @@ static hipError_t create_priority_stream(hipStream_t* s)
     return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
 }
 
+// The tracker's stream.  ICELK_TRACKER_CU_SKIP=<n> (experiment): the stream may not use the CUs of the first n mask bits,
+// which leaves them to the detector / copy streams whose short kernels otherwise queue for wave slots behind the
+// thousands of pending tracker workgroups.
+static hipError_t create_compute_stream(hipStream_t* s)
+{
+    const char* e = getenv("ICELK_TRACKER_CU_SKIP");
+    const int skip = e ? atoi(e) : 0;
+    if (skip <= 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    uint32_t mask[8];
+    for (int i = 0; i < 8; i++) mask[i] = 0xffffffffu;
+    for (int i = 0; i < skip && i < 256; i++) mask[i >> 5] &= ~(1u << (i & 31));
+    return hipExtStreamCreateWithCUMask(s, 8, mask);
+}
+
 static void destroy_ctx(Ctx* c)
 {
     if (!c) return;
@@ -394,7 +456,7 @@ static void destroy_ctx(Ctx* c)
         if (s.base) hipFree(s.base);
         if (s.ready) hipEventDestroy(s.ready);
         if (s.frame_ev) hipEventDestroy(s.frame_ev);
-        if (s.used) hipEventDestroy(s.used);
+        if (s.used_own) hipEventDestroy(s.used_own);
         if (s.det_used) hipEventDestroy(s.det_used);
     }
     if (c->det_stream) hipStreamSynchronize(c->det_stream);
@@ -402,10 +464,16 @@ static void destroy_ctx(Ctx* c)
     if (c->det_done) hipEventDestroy(c->det_done);
     if (c->corners_free) hipEventDestroy(c->corners_free);
     if (c->det_stream) hipStreamDestroy(c->det_stream);
+    if (c->tail_stream) {
+        hipStreamSynchronize(c->tail_stream);
+        hipStreamDestroy(c->tail_stream);
+    }
+    for (auto& e : c->acc_read)
+        if (e) hipEventDestroy(e);
     if (c->eig_stream) hipStreamDestroy(c->eig_stream);
     if (c->seg_ready) hipEventDestroy(c->seg_ready);
     for (auto& b : c->sb)
-        if (b.used) hipEventDestroy(b.used);
+        if (b.used_own) hipEventDestroy(b.used_own);
     for (auto& e : c->eo)
         if (e.done) hipEventDestroy(e.done);
     if (c->h_counts) hipHostFree(c->h_counts);
@@ -413,12 +481,16 @@ static void destroy_ctx(Ctx* c)
     void* ptrs[] = {c->d_bgr, c->d_mask, c->d_p0, c->d_p1, c->d_p0r, c->d_err_f, c->d_err_b, c->d_dist, c->d_corners,
                     c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.cand, c->D.cand_count,
                     c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.chunk_tot, c->D.cell_cand, c->D.state, c->D.undecided,
-                    c->D.acc, c->D.acc_sorted, c->D.acc_count, c->eo[0].raw, c->eo[1].raw, c->eo[0].blk_count, c->eo[1].blk_count,
-                    c->eo[0].max_key, c->eo[1].max_key, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->sb[0].live, c->sb[1].live, c->sb[0].alive, c->sb[1].alive, c->sb[0].order, c->sb[0].order_border, c->sb[1].order_border,
-                    c->sb[1].order, c->sb[0].tracks, c->sb[1].tracks, c->sb[0].quality, c->sb[1].quality, c->d_tracked,
+                    c->acc_buf[0], c->acc_buf[1], c->D.acc_sorted, c->D.acc_count, c->eo[0].raw, c->eo[1].raw, c->eo[0].blk_count, c->eo[1].blk_count,
+                    c->eo[0].max_key, c->eo[1].max_key, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->d_tracked,
                     c->d_out_tracks, c->d_out_quality, c->d_proj, c->d_keep};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    for (auto& S : c->sb) {
+        void* sp[] = {S.live, S.alive, S.order, S.order_border, S.tracks, S.quality};
+        for (void* p : sp)
+            if (p) hipFree(p);
+    }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     delete c;
@@ -480,8 +552,8 @@ static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
         e.mask_gen == c->mask_gen)
         return ICELK_OK;   // already there
     const hipStream_t es = c->eig_stream;
+    // level 0 only: `ready` would also wait for a pyramid built ahead, which the detector never reads
     HIPCHK(c, hipStreamWaitEvent(es, s.frame_ev, 0));
-    if (s.pending) HIPCHK(c, hipStreamWaitEvent(es, s.ready, 0));
     HIPCHK(c, hipMemsetAsync(e.max_key, 0, sizeof(unsigned), es));
     DetectScratch T = c->D;
     T.raw = e.raw;
@@ -530,11 +602,10 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
         ncell = (size_t)((w + cell - 1) / cell) * ((h + cell - 1) / cell);
         if (ncell + 1 > c->ncell_cap) FAIL(c, ICELK_ECAP, "cell grid larger than allocated");
     }
-    // the frame must be in the slot (ingest on the compute or the copy stream) and the previous corner list
-    // must have been consumed before this detection overwrites it; nothing else orders the two streams
-    HIPCHK(c, hipStreamWaitEvent(ds, s.frame_ev, 0));
-    if (s.pending) HIPCHK(c, hipStreamWaitEvent(ds, s.ready, 0));
-    HIPCHK(c, hipStreamWaitEvent(ds, c->corners_free, 0));
+    // the frame must be in the slot (ingest on the compute or the copy stream), and the tail that sorted the buffer of
+    // accepted keys this detection writes (two detections ago) must have read it; nothing else orders the streams
+    HIPCHK(c, hipStreamWaitEvent(ds, s.frame_ev, 0));   // level 0 only (see detect_prepare)
+    HIPCHK(c, hipStreamWaitEvent(ds, c->acc_read[c->acc_idx], 0));
     const bool generic = getenv("ICELK_GENERIC_CORNERS") != nullptr;
     // counters are normally left zeroed by the previous detection (the reset runs after its last kernel,
     // off the critical path); reset here only the first time or when the cell grid grew
@@ -588,6 +659,10 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
     J.active = false;
     *n_out = 0;
     const hipStream_t ds = c->det_stream;
+    // everything after the host round trip: on the tail stream (the detection stream has been waited for: whatever it
+    // produced is there), except when the keys to sort are not double buffered (minDistance < 1)
+    const hipStream_t ts = (J.min_distance >= 1 && c->use_tail_stream) ? c->tail_stream : ds;
+    c->corners_stream = ts;
     DetectScratch& D = c->D;
     int rc = fetch_counts(c);   // the one host round trip of a detection: {candidates, accepted, undecided}
     if (rc) return rc;
@@ -616,13 +691,20 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
         c->last_candidates = c->h_counts[0];
         c->last_accepted = total;
         if (total == 0) return ICELK_OK;
-        sort_keys_desc(ds, D, D.acc, D.acc_sorted, total);
+        sort_keys_desc(ts, D, D.acc, D.acc_sorted, total);
         sorted = D.acc_sorted;
+        if (ts != ds) {
+            // the next min-distance stage writes the other buffer
+            HIPCHK(c, hipEventRecord(c->acc_read[c->acc_idx], ts));
+            c->acc_idx ^= 1;
+            D.acc = c->acc_buf[c->acc_idx];
+        }
     } else {
         total = c->h_counts[0];
         c->last_candidates = total;
         c->last_accepted = total;
         if (total == 0) return ICELK_OK;
+        HIPCHK(c, hipStreamWaitEvent(ds, c->det_done, 0));   // sort scratch: an earlier tail may still use it
         sort_keys_desc(ds, D, D.cand, D.cell_cand, total);
         sorted = D.cell_cand;
     }
@@ -631,13 +713,14 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
     int n = total;
     if (max_corners > 0 && n > max_corners) n = max_corners;
     if (n > cap || n > c->max_pts) FAIL(c, ICELK_ECAP, "more corners than the output capacity (raise max_pts)");
+    HIPCHK(c, hipStreamWaitEvent(ts, c->corners_free, 0));   // the previous corner list has been consumed
     {
-        ProfScope p(c, K_EMIT, ds);
-        launch_emit_corners(ds, sorted, n, J.w, c->d_corners);
+        ProfScope p(c, K_EMIT, ts);
+        launch_emit_corners(ts, sorted, n, J.w, c->d_corners);
     }
     rc = check_launch(c, "emit");
     if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->det_done, ds));
+    HIPCHK(c, hipEventRecord(c->det_done, ts));
     launch_detect_reset(ds, D, (int)J.ncell, true);   // for the next detection
     c->reset_ncell = J.ncell;
     c->counters_clean = true;
@@ -664,31 +747,18 @@ static int seg_wait(Ctx* c)
     return ICELK_OK;
 }
 
-// shared by icelk_seg_track / icelk_seg_track_async
-static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int win_h, int max_level, int crit_type,
-                          int max_count, double epsilon, double min_eig_threshold, float fb_threshold)
+// the segment-pair job of set `set` across slots s0 -> s1; `primary` jobs also fill the handle's per-feature diagnostic
+// arrays (positions, status, error, distance of the latest launch) -- one job per launch can own them
+static LKJob seg_job(Ctx* c, int set, const Slot& s0, const Slot& s1, const LKParams& P, bool primary)
 {
-    int rc = check_slot(c, slot_prev, true);
-    if (!rc) rc = check_slot(c, slot_next, true);
-    if (rc) return rc;
-    if (!c->seg_active) FAIL(c, ICELK_ESTATE, "icelk_seg_detect has not been called");
-    if (c->seg_vert >= kMaxVert) FAIL(c, ICELK_ECAP, "segment longer than the device track table");
-    Slot& s0 = c->slots[slot_prev];
-    Slot& s1 = c->slots[slot_next];
-    if (s0.w != s1.w || s0.h != s1.h) FAIL(c, ICELK_EARG, "frame sizes differ");
-    LKParams P;
-    rc = make_lk_params(c, s0.w, s0.h, win_w, win_h, max_level, crit_type, max_count, epsilon, 0, min_eig_threshold,
-                        fb_threshold, &P);
-    if (rc) return rc;
-    rc = ensure_pyramid(c, slot_prev, P.top_level);
-    if (!rc) rc = ensure_pyramid(c, slot_next, P.top_level);
-    if (rc) return rc;
-    rc = seg_wait(c);
-    if (rc) return rc;
-    Ctx::SegBuf& S = c->sb[c->sb_cur];
-    if (c->seg_upper > 0) {
-        LKBuffers B{};
-        B.p_in = S.live;
+    Ctx::SegBuf& S = c->sb[set];
+    LKJob j{};
+    j.I = pyramid_of(s0);
+    j.J = pyramid_of(s1);
+    j.n = S.upper;
+    LKBuffers& B = j.B;
+    B.p_in = S.live;
+    if (primary) {
         B.p_fwd = c->d_p1;
         B.st_fwd = c->d_st_f;
         B.err_fwd = c->d_err_f;
@@ -697,43 +767,170 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
         B.err_bwd = c->d_err_b;
         B.dist = c->d_dist;
         B.valid = c->d_valid;
-        B.seg_alive = S.alive;
-        B.order = c->use_order ? S.order : nullptr;
-        B.order_border = c->use_order ? S.order_border : nullptr;
+    }
+    B.seg_alive = S.alive;
+    B.order = c->use_order ? S.order : nullptr;
+    B.order_border = c->use_order ? S.order_border : nullptr;
+    // Dealing the sorted sequence to the XCDs pays while neighbouring windows barely overlap (C2: 244 -> 233 us);
+    // with dense features every XCD would work on one spot of the frame at a time and its L2 channels
+    // serialise (REF: 2 060 us walking the table linearly, 2 680 us dealt, 2 230 us unsorted)
+    const double overlap = (double)(P.win_w + 12) * (P.win_h + 12) * S.upper / ((double)s0.w * s0.h);
+    B.order_plain = overlap >= 2.0 ? 1 : 0;
+    B.seg_xy = S.live;
+    B.seg_tracks = S.tracks;
+    B.seg_quality = S.quality;
+    B.seg_vert = S.vert;
+    B.seg_max_vert = kMaxVert;
+    B.seg_tracked = c->d_tracked;
+    return j;
+}
+
+// one event behind a tracker launch, for everything the launch read or wrote
+static int record_launch(Ctx* c, hipEvent_t* ev)
+{
+    *ev = c->launch_ev[c->launch_seq++ % kLaunchEvents];
+    HIPCHK(c, hipEventRecord(*ev, c->stream));
+    return ICELK_OK;
+}
+
+static void seg_launched(Ctx* c, hipEvent_t ev, int set, int slot_prev, int slot_next)
+{
+    c->slots[slot_prev].used = ev;
+    c->slots[slot_next].used = ev;
+    c->sb[set].used = ev;
+}
+
+// a pair waiting for a partner goes out on its own
+static int flush_deferred(Ctx* c)
+{
+    if (!c->defer.pending) return ICELK_OK;
+    Ctx::Deferred& d = c->defer;
+    d.pending = false;
+    int rc;
+    {
+        ProfScope p(c, K_LK_FB);
+        rc = launch_lk(c->stream, d.job.I, d.job.J, d.job.B, d.job.n, d.P, true);
+    }
+    if (rc) FAIL(c, rc, "unsupported window size");
+    rc = check_launch(c, "lk_fb");
+    if (rc) return rc;
+    hipEvent_t ev;
+    rc = record_launch(c, &ev);
+    if (rc) return rc;
+    seg_launched(c, ev, d.set, d.slot_prev, d.slot_next);
+    return ICELK_OK;
+}
+
+// before a slot's frame or pyramid is overwritten: a waiting pair that reads it must have been launched
+static int flush_deferred_slot(Ctx* c, int slot)
+{
+    if (c->defer.pending && (c->defer.slot_prev == slot || c->defer.slot_next == slot)) return flush_deferred(c);
+    return ICELK_OK;
+}
+
+static bool same_lk_params(const LKParams& a, const LKParams& b)
+{
+    return a.win_w == b.win_w && a.win_h == b.win_h && a.top_level == b.top_level && a.max_count == b.max_count &&
+           a.eps2 == b.eps2 && a.flags == b.flags && a.min_eig_thr == b.min_eig_thr && a.fb_thr == b.fb_thr &&
+           a.margin == b.margin && a.dist_form == b.dist_form;
+}
+
+// shared by icelk_seg_track / icelk_seg_track_async / icelk_seg_track_defer
+static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int win_h, int max_level, int crit_type,
+                          int max_count, double epsilon, double min_eig_threshold, float fb_threshold, bool defer)
+{
+    int rc = check_slot(c, slot_prev, true);
+    if (!rc) rc = check_slot(c, slot_next, true);
+    if (rc) return rc;
+    if (!c->seg_active) FAIL(c, ICELK_ESTATE, "icelk_seg_detect has not been called");
+    Ctx::SegBuf& S = c->sb[c->sb_cur];
+    if (S.vert >= kMaxVert) FAIL(c, ICELK_ECAP, "segment longer than the device track table");
+    Slot& s0 = c->slots[slot_prev];
+    Slot& s1 = c->slots[slot_next];
+    if (s0.w != s1.w || s0.h != s1.h) FAIL(c, ICELK_EARG, "frame sizes differ");
+    LKParams P;
+    rc = make_lk_params(c, s0.w, s0.h, win_w, win_h, max_level, crit_type, max_count, epsilon, 0, min_eig_threshold,
+                        fb_threshold, &P);
+    if (rc) return rc;
+    // a waiting pair of THIS segment comes first (pairs of a segment are sequential)
+    if (c->defer.pending && c->defer.set == c->sb_cur) {
+        rc = flush_deferred(c);
+        if (rc) return rc;
+    }
+    rc = ensure_pyramid(c, slot_prev, P.top_level);
+    if (!rc) rc = ensure_pyramid(c, slot_next, P.top_level);
+    if (rc) return rc;
+    rc = seg_wait(c);
+    if (rc) return rc;
+    if (S.upper > 0) {
         // tiles (half window + search margin) of a feature this close to the edge reach over it at the upper levels
         c->border_px = c->border_first ? ((std::max(win_w, win_h) / 2 + 6 + 2) << std::max(P.top_level - 1, 0)) : 0;
-        // Dealing the sorted sequence to the XCDs pays while neighbouring windows barely overlap (C2: 244 -> 233 us);
-        // with dense features every XCD would work on one spot of the frame at a time and its L2 channels
-        // serialise (REF: 2 060 us walking the table linearly, 2 680 us dealt, 2 230 us unsorted)
-        const double overlap = (double)(win_w + 12) * (win_h + 12) * c->seg_upper / ((double)s0.w * s0.h);
-        B.order_plain = overlap >= 2.0 ? 1 : 0;
-        B.seg_xy = S.live;
-        B.seg_tracks = S.tracks;
-        B.seg_quality = S.quality;
-        B.seg_vert = c->seg_vert;
-        B.seg_max_vert = kMaxVert;
-        B.seg_tracked = c->d_tracked;
-        if (c->prof) {
-            B.iters = c->d_iters;
-            c->iters_n = c->seg_upper;
-            hipMemsetAsync(c->d_iters, 0xff, sizeof(uint32_t) * (size_t)c->seg_upper, c->stream);   // dead tracks stay ~0
+        LKJob job = seg_job(c, c->sb_cur, s0, s1, P, true);
+        const bool diag = c->d_stamps != nullptr;   // workgroup stamps describe ONE job: no pairing while they are on
+        if (defer && !c->defer.pending && !diag) {
+            // nothing goes out now: the pair waits for the first pair of the next segment (or another waiting pair)
+            Ctx::Deferred& d = c->defer;
+            d.pending = true;
+            d.set = c->sb_cur;
+            d.slot_prev = slot_prev;
+            d.slot_next = slot_next;
+            d.job = job;
+            d.P = P;
+            S.vert += 1;
+            return ICELK_OK;
         }
-        if (c->d_stamps) {
-            B.stamps = c->d_stamps;
-            hipMemsetAsync(c->d_stamps, 0, 3 * c->stamps_cap * 8, c->stream);
+        bool paired = false;
+        if (c->defer.pending) {
+            Ctx::Deferred& d = c->defer;
+            if (!diag && same_lk_params(d.P, P)) {
+                LKJob other = d.job;
+                // the diagnostic arrays belong to the job of the current segment
+                other.B.p_fwd = other.B.p_bwd = other.B.err_fwd = other.B.err_bwd = other.B.dist = nullptr;
+                other.B.st_fwd = other.B.st_bwd = other.B.valid = nullptr;
+                {
+                    ProfScope p(c, K_LK_FB_PAIR);
+                    paired = launch_lk_pair(c->stream, other, job, P);
+                }
+                if (paired) {
+                    d.pending = false;
+                    rc = check_launch(c, "lk_fb_pair");
+                    if (rc) return rc;
+                }
+            }
+            if (!paired) {
+                rc = flush_deferred(c);
+                if (rc) return rc;
+            }
         }
-        {
-            ProfScope p(c, K_LK_FB);
-            rc = launch_lk(c->stream, pyramid_of(s0), pyramid_of(s1), B, c->seg_upper, P, true);
+        if (!paired) {
+            LKBuffers& B = job.B;
+            if (c->prof) {
+                B.iters = c->d_iters;
+                c->iters_n = S.upper;
+                hipMemsetAsync(c->d_iters, 0xff, sizeof(uint32_t) * (size_t)S.upper, c->stream);   // dead tracks stay ~0
+            }
+            if (c->d_stamps) {
+                B.stamps = c->d_stamps;
+                hipMemsetAsync(c->d_stamps, 0, 3 * c->stamps_cap * 8, c->stream);
+            }
+            {
+                ProfScope p(c, K_LK_FB);
+                rc = launch_lk(c->stream, job.I, job.J, B, job.n, P, true);
+            }
+            if (rc) FAIL(c, rc, "unsupported window size");
+            rc = check_launch(c, "lk_fb");
+            if (rc) return rc;
         }
-        if (rc) FAIL(c, rc, "unsupported window size");
-        rc = check_launch(c, "lk_fb");
-        if (!rc) rc = mark_used(c, slot_prev);
-        if (!rc) rc = mark_used(c, slot_next);
+        hipEvent_t ev;
+        rc = record_launch(c, &ev);
         if (rc) return rc;
-        HIPCHK(c, hipEventRecord(S.used, c->stream));
+        if (paired) seg_launched(c, ev, c->defer.set, c->defer.slot_prev, c->defer.slot_next);
+        seg_launched(c, ev, c->sb_cur, slot_prev, slot_next);
+    } else if (c->defer.pending && !defer) {
+        rc = flush_deferred(c);
+        if (rc) return rc;
     }
-    c->seg_vert += 1;
+    S.vert += 1;
     return ICELK_OK;
 }
 
@@ -803,13 +1000,16 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         destroy_ctx(c);
         return code;
     };
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+    if (create_compute_stream(&c->own_stream) != hipSuccess ||
+        // uploads and pyramids built ahead: short kernels the NEXT tracker launch waits for, issued beside the current one
+        (getenv("ICELK_COPY_STREAM_NORMAL") ? hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)
+                                            : create_priority_stream(&c->copy_stream)) != hipSuccess ||
         create_priority_stream(&c->det_stream) != hipSuccess ||
+        create_priority_stream(&c->tail_stream) != hipSuccess ||
+        hipEventCreateWithFlags(&c->acc_read[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->acc_read[1], hipEventDisableTiming) != hipSuccess ||
         create_priority_stream(&c->eig_stream) != hipSuccess ||
         hipEventCreateWithFlags(&c->seg_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->sb[0].used, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->sb[1].used, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->eo[0].done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->eo[1].done, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), 64, hipHostMallocMapped) != hipSuccess ||
@@ -827,7 +1027,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         s.bytes = sb;
         if (hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.frame_ev, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.used, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.used_own, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.det_used, hipEventDisableTiming) != hipSuccess) {
             c->err = "hipEventCreate failed";
             return fail(ICELK_EHIP);
@@ -851,20 +1051,25 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &D.cell_count, c->ncell_cap)) || (rc = dmalloc(c, &D.cell_start, c->ncell_cap)) ||
         (rc = dmalloc(c, &D.cell_fill, c->ncell_cap)) || (rc = dmalloc(c, &D.chunk_tot, (c->ncell_cap / 2048 + 2) * 32)) || (rc = dmalloc(c, &D.cell_cand, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.state, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.undecided, 64)) ||
-        (rc = dmalloc(c, &D.acc, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.acc_sorted, (size_t)D.cand_cap)) ||
+        (rc = dmalloc(c, &c->acc_buf[0], (size_t)D.cand_cap)) || (rc = dmalloc(c, &c->acc_buf[1], (size_t)D.cand_cap)) ||
+        (rc = dmalloc(c, &D.acc_sorted, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, &c->eo[0].blk_count, candidate_blocks(max_w, max_h) * 4)) ||
         (rc = dmalloc(c, &c->eo[1].blk_count, candidate_blocks(max_w, max_h) * 4)) ||
         (rc = dmalloc(c, &D.key_hist, 1 << 16)) || (rc = dmalloc(c, &D.prune_key, 1)) || (rc = dmalloc(c, (uint8_t**)&D.sort_tmp, D.sort_tmp_bytes)) ||
-        (rc = dmalloc(c, &c->sb[0].live, 2 * np)) || (rc = dmalloc(c, &c->sb[0].alive, np)) || (rc = dmalloc(c, &c->sb[0].order, np)) || (rc = dmalloc(c, &c->sb[0].order_border, 1)) || (rc = dmalloc(c, &c->sb[1].order_border, 1)) ||
-        (rc = dmalloc(c, &c->sb[1].live, 2 * np)) || (rc = dmalloc(c, &c->sb[1].alive, np)) || (rc = dmalloc(c, &c->sb[1].order, np)) ||
-        (rc = dmalloc(c, &c->sb[0].tracks, np * kMaxVert * 2)) || (rc = dmalloc(c, &c->sb[1].tracks, np * kMaxVert * 2)) ||
-        (rc = dmalloc(c, &c->sb[0].quality, np * (kMaxVert - 1))) || (rc = dmalloc(c, &c->sb[1].quality, np * (kMaxVert - 1))) ||
         (rc = dmalloc(c, &c->d_tracked, 64)) || (rc = dmalloc(c, &c->d_out_tracks, np * kMaxVert * 2)) ||
         (rc = dmalloc(c, &c->d_out_quality, np * (kMaxVert - 1))))
         return fail(rc);
+    D.acc = c->acc_buf[0];
+    for (auto& S : c->sb)
+        if ((rc = dmalloc(c, &S.live, 2 * np)) || (rc = dmalloc(c, &S.alive, np)) || (rc = dmalloc(c, &S.order, np)) ||
+            (rc = dmalloc(c, &S.order_border, 1)) || (rc = dmalloc(c, &S.tracks, np * kMaxVert * 2)) ||
+            (rc = dmalloc(c, &S.quality, np * (kMaxVert - 1))))
+            return fail(rc);
     c->use_order = getenv("ICELK_NO_ORDER") == nullptr;
     c->border_first = getenv("ICELK_NO_BORDER_FIRST") == nullptr;
     c->pyr_per_level = getenv("ICELK_PYR_PER_LEVEL") != nullptr;
+    c->use_tail_stream = getenv("ICELK_NO_TAIL_STREAM") == nullptr;
+    c->pyr_ahead_one_wave = getenv("ICELK_PYR_AHEAD_WIDE") == nullptr;
     if (!c->border_first) c->border_px = 0;
     if ((rc = dmalloc(c, &c->d_iters, (size_t)max_pts))) return fail(rc);
     if (const char* sp = getenv("ICELK_LK_STAMPS")) {
@@ -907,11 +1112,14 @@ int icelk_sync(icelk_t* h)
     if (!h) return ICELK_EARG;
     Ctx* c = C(h);
     HIPCHK(c, hipSetDevice(c->device));
+    int rcf = flush_deferred(c);   // a pair waiting for a partner counts as issued work
+    if (rcf) return rcf;
     // every stream of the handle: uploads / pyramids built ahead, candidate kernels of a prepared detection
     // (icelk_seg_detect_prepare), the min-distance / sort / emit stage, tracker launches
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->eig_stream));
     HIPCHK(c, hipStreamSynchronize(c->det_stream));
+    HIPCHK(c, hipStreamSynchronize(c->tail_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ICELK_OK;
 }
@@ -1079,6 +1287,7 @@ int icelk_drop_pyramid(icelk_t* h, int slot)
     if (!h) return ICELK_EARG;
     Ctx* c = C(h);
     int rc = check_slot(c, slot, true);
+    if (!rc) rc = flush_deferred_slot(c, slot);
     if (rc) return rc;
     c->slots[slot].levels_built = 1;
     return ICELK_OK;
@@ -1361,6 +1570,7 @@ int icelk_min_eig_map(icelk_t* h, int slot, int block_size, float* host_out, int
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));       // the frame is in place
     HIPCHK(c, hipStreamSynchronize(c->det_stream));   // the detector scratch is free
+    HIPCHK(c, hipStreamSynchronize(c->tail_stream));
     {
         ProfScope p(c, K_EIG);
         launch_detect_reset(c->stream, c->D, 0, true);
@@ -1390,8 +1600,8 @@ int icelk_good_features(icelk_t* h, int slot, int use_mask, int max_corners, dou
     int rc = detect_core(c, slot, use_mask, max_corners, quality_level, min_distance, block_size, cap, &n);
     if (rc) return rc;
     if (n > 0) {
-        HIPCHK(c, hipMemcpyAsync(out_xy, c->d_corners, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->det_stream));
-        HIPCHK(c, hipStreamSynchronize(c->det_stream));
+        HIPCHK(c, hipMemcpyAsync(out_xy, c->d_corners, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->corners_stream));
+        HIPCHK(c, hipStreamSynchronize(c->corners_stream));
     }
     *out_n = n;
     return ICELK_OK;
@@ -1435,8 +1645,8 @@ static int seg_stage(Ctx* c, int max_corners, int* out_n)
     if (rc) return rc;
     // the new segment goes into the other set, on the detection stream right behind the corner list; launches
     // that still touch that set (the segment before the closing one) must be through
-    Ctx::SegBuf& nb = c->sb[c->sb_cur ^ 1];
-    const hipStream_t ds = c->det_stream;
+    Ctx::SegBuf& nb = c->sb[(c->sb_cur + 1) % kSegSets];
+    const hipStream_t ds = c->corners_stream;   // right behind the corner list
     HIPCHK(c, hipStreamWaitEvent(ds, nb.used, 0));
     launch_seg_init(ds, c->d_corners, n, nb.live, nb.alive, nb.tracks, kMaxVert);
     if (c->use_order) launch_seg_order(ds, c->d_corners, n, c->job.w, c->job.h, c->border_px, nb.order, nb.order_border);
@@ -1453,11 +1663,17 @@ static int seg_stage(Ctx* c, int max_corners, int* out_n)
 static int seg_switch(Ctx* c)
 {
     if (!c->seg_staged) FAIL(c, ICELK_ESTATE, "no staged segment (icelk_seg_detect_stage has not been called)");
+    // a pair still waiting from before the previous switch has found no partner
+    if (c->defer.pending && c->defer.set != c->sb_cur) {
+        int rc = flush_deferred(c);
+        if (rc) return rc;
+    }
     c->seg_staged = false;
-    c->sb_cur ^= 1;
+    c->closed_valid = c->seg_active;
+    c->sb_cur = (c->sb_cur + 1) % kSegSets;
     c->seg_ready_pending = true;
-    c->seg_vert = 1;
-    c->seg_upper = c->staged_n;
+    c->sb[c->sb_cur].vert = 1;
+    c->sb[c->sb_cur].upper = c->staged_n;
     c->seg_active = true;
     return ICELK_OK;
 }
@@ -1501,7 +1717,25 @@ int icelk_seg_track_async(icelk_t* h, int slot_prev, int slot_next, int win_w, i
     Ctx* c = C(h);
     HIPCHK(c, hipSetDevice(c->device));
     return seg_track_core(c, slot_prev, slot_next, win_w, win_h, max_level, crit_type, max_count, epsilon,
-                          min_eig_threshold, fb_threshold);
+                          min_eig_threshold, fb_threshold, false);
+}
+
+int icelk_seg_track_defer(icelk_t* h, int slot_prev, int slot_next, int win_w, int win_h, int max_level, int crit_type,
+                          int max_count, double epsilon, double min_eig_threshold, float fb_threshold)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    return seg_track_core(c, slot_prev, slot_next, win_w, win_h, max_level, crit_type, max_count, epsilon,
+                          min_eig_threshold, fb_threshold, true);
+}
+
+int icelk_seg_flush(icelk_t* h)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    return flush_deferred(c);
 }
 
 // run the projection kernel over `n` gathered tracks sitting in d_tracks_in and bring the results to the host
@@ -1576,13 +1810,13 @@ int icelk_seg_project(icelk_t* h, const icelk_camera_t* cam, const icelk_utm_fil
     int n = 0;
     rc = icelk_seg_live(h, &n, nullptr);
     if (rc) return rc;
-    const int nv = c->seg_vert;
+    Ctx::SegBuf& S = c->sb[c->sb_cur];
+    const int nv = S.vert;
     if (out_n) *out_n = n;
     if (out_vectors) *out_vectors = nv - 1;
     if (n > cap || nv - 1 > max_vectors) FAIL(c, ICELK_ECAP, "host buffers too small");
     if (n == 0) return ICELK_OK;
-    launch_seg_gather(c->stream, c->sb[c->sb_cur].alive, c->seg_upper, c->sb[c->sb_cur].tracks, c->sb[c->sb_cur].quality, nv, kMaxVert, c->d_out_tracks,
-                      c->d_out_quality);
+    launch_seg_gather(c->stream, S.alive, S.upper, S.tracks, S.quality, nv, kMaxVert, c->d_out_tracks, c->d_out_quality);
     rc = check_launch(c, "seg_gather");
     if (rc) return rc;
     return project_core(c, c->d_out_tracks, n, nv, cam, filt, max_vectors, x, y, u, v, speed, keep);
@@ -1685,23 +1919,42 @@ int icelk_grid_bin(icelk_t* h, const double* x, const double* y, const double* u
     return ICELK_OK;
 }
 
-int icelk_seg_live(icelk_t* h, int* out_live, int64_t* out_tracked_total)
+// which segment a read-out addresses: the current one, or the one closed by the latest switch
+static int seg_pick(Ctx* c, bool closed, int* set)
 {
-    if (!h) return ICELK_EARG;
-    Ctx* c = C(h);
-    HIPCHK(c, hipSetDevice(c->device));
     if (!c->seg_active) FAIL(c, ICELK_ESTATE, "icelk_seg_detect has not been called");
-    int rcw = seg_wait(c);
-    if (rcw) return rcw;
-    launch_seg_stats(c->stream, c->sb[c->sb_cur].alive, c->seg_upper, c->d_tracked, c->h_seg);
-    int rc0 = check_launch(c, "seg_stats");
-    if (rc0) return rc0;
+    if (closed && !c->closed_valid) FAIL(c, ICELK_ESTATE, "no closed segment");
+    *set = closed ? (c->sb_cur + kSegSets - 1) % kSegSets : c->sb_cur;
+    // its waiting pair, if any, belongs to the result
+    if (c->defer.pending && c->defer.set == *set) {
+        int rc = flush_deferred(c);
+        if (rc) return rc;
+    }
+    return closed ? ICELK_OK : seg_wait(c);
+}
+
+static int seg_live_core(Ctx* c, bool closed, int* out_live, int64_t* out_tracked_total)
+{
+    int set = 0;
+    int rc = seg_pick(c, closed, &set);
+    if (rc) return rc;
+    launch_seg_stats(c->stream, c->sb[set].alive, c->sb[set].upper, c->d_tracked, c->h_seg);
+    rc = check_launch(c, "seg_stats");
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int n = (int)c->h_seg[0];
     const unsigned long long t = c->h_seg[1];
     if (out_live) *out_live = n;
     if (out_tracked_total) *out_tracked_total = (int64_t)t;
     return ICELK_OK;
+}
+
+int icelk_seg_live(icelk_t* h, int* out_live, int64_t* out_tracked_total)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    return seg_live_core(c, false, out_live, out_tracked_total);
 }
 
 int icelk_seg_track(icelk_t* h, int slot_prev, int slot_next, int win_w, int win_h, int max_level, int crit_type,
@@ -1713,23 +1966,20 @@ int icelk_seg_track(icelk_t* h, int slot_prev, int slot_next, int win_w, int win
     return icelk_seg_live(h, out_live, nullptr);
 }
 
-int icelk_seg_read(icelk_t* h, float* tracks, float* quality, int cap, int max_vertices, int* out_n, int* out_vertices)
+static int seg_read_core(Ctx* c, bool closed, float* tracks, float* quality, int cap, int max_vertices, int* out_n,
+                         int* out_vertices)
 {
-    if (!h) return ICELK_EARG;
-    Ctx* c = C(h);
-    HIPCHK(c, hipSetDevice(c->device));
-    if (!c->seg_active) FAIL(c, ICELK_ESTATE, "icelk_seg_detect has not been called");
     int n = 0;
-    int rc = icelk_seg_live(h, &n, nullptr);
+    int rc = seg_live_core(c, closed, &n, nullptr);
     if (rc) return rc;
-    const int nv = c->seg_vert;
+    Ctx::SegBuf& S = c->sb[closed ? (c->sb_cur + kSegSets - 1) % kSegSets : c->sb_cur];
+    const int nv = S.vert;
     if (out_n) *out_n = n;
     if (out_vertices) *out_vertices = nv;
     if (!tracks && !quality) return ICELK_OK;
     if (n > cap || nv > max_vertices) FAIL(c, ICELK_ECAP, "host track buffers too small");
     if (n == 0) return ICELK_OK;
-    launch_seg_gather(c->stream, c->sb[c->sb_cur].alive, c->seg_upper, c->sb[c->sb_cur].tracks, c->sb[c->sb_cur].quality, nv, kMaxVert, c->d_out_tracks,
-                      c->d_out_quality);
+    launch_seg_gather(c->stream, S.alive, S.upper, S.tracks, S.quality, nv, kMaxVert, c->d_out_tracks, c->d_out_quality);
     rc = check_launch(c, "seg_gather");
     if (rc) return rc;
     // host layout: (n, max_vertices, 2) and (n, max_vertices-1) with the caller's vertex dimension
@@ -1743,27 +1993,60 @@ int icelk_seg_read(icelk_t* h, float* tracks, float* quality, int cap, int max_v
     return ICELK_OK;
 }
 
+int icelk_seg_read(icelk_t* h, float* tracks, float* quality, int cap, int max_vertices, int* out_n, int* out_vertices)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    return seg_read_core(c, false, tracks, quality, cap, max_vertices, out_n, out_vertices);
+}
+
+int icelk_seg_read_closed(icelk_t* h, float* tracks, float* quality, int cap, int max_vertices, int* out_n,
+                          int* out_vertices)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    return seg_read_core(c, true, tracks, quality, cap, max_vertices, out_n, out_vertices);
+}
+
+static int seg_archive_core(Ctx* c, bool closed, void* dev_tracks, void* dev_quality, void* dev_count, int cap_rows,
+                            int* out_vertices)
+{
+    if (!dev_tracks || !dev_count) FAIL(c, ICELK_EARG, "null device buffer");
+    int set = 0;
+    int rc = seg_pick(c, closed, &set);
+    if (rc) return rc;
+    Ctx::SegBuf& S = c->sb[set];
+    if (cap_rows < S.upper) FAIL(c, ICELK_ECAP, "archive rows < tracks of the segment");
+    const int nv = S.vert;
+    if (out_vertices) *out_vertices = nv;
+    // quality is optional: the gather kernel writes it next to the tracks; without a destination it goes to the
+    // handle's own read-out buffer
+    launch_seg_gather(c->stream, S.alive, S.upper, S.tracks, S.quality, nv, kMaxVert, reinterpret_cast<float*>(dev_tracks),
+                      dev_quality ? reinterpret_cast<float*>(dev_quality) : c->d_out_quality, reinterpret_cast<int*>(dev_count));
+    rc = check_launch(c, "seg_archive");
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(S.used_own, c->stream));
+    S.used = S.used_own;
+    return ICELK_OK;
+}
+
 int icelk_seg_archive(icelk_t* h, void* dev_tracks, void* dev_quality, void* dev_count, int cap_rows, int* out_vertices)
 {
     if (!h) return ICELK_EARG;
     Ctx* c = C(h);
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->seg_active) FAIL(c, ICELK_ESTATE, "icelk_seg_detect has not been called");
-    if (!dev_tracks || !dev_count) FAIL(c, ICELK_EARG, "null device buffer");
-    if (cap_rows < c->seg_upper) FAIL(c, ICELK_ECAP, "archive rows < tracks of the segment");
-    int rc = seg_wait(c);
-    if (rc) return rc;
-    const int nv = c->seg_vert;
-    if (out_vertices) *out_vertices = nv;
-    Ctx::SegBuf& S = c->sb[c->sb_cur];
-    // quality is optional: the gather kernel writes it next to the tracks; without a destination it goes to the
-    // handle's own read-out buffer
-    launch_seg_gather(c->stream, S.alive, c->seg_upper, S.tracks, S.quality, nv, kMaxVert, reinterpret_cast<float*>(dev_tracks),
-                      dev_quality ? reinterpret_cast<float*>(dev_quality) : c->d_out_quality, reinterpret_cast<int*>(dev_count));
-    rc = check_launch(c, "seg_archive");
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(S.used, c->stream));
-    return ICELK_OK;
+    return seg_archive_core(c, false, dev_tracks, dev_quality, dev_count, cap_rows, out_vertices);
+}
+
+int icelk_seg_archive_closed(icelk_t* h, void* dev_tracks, void* dev_quality, void* dev_count, int cap_rows,
+                             int* out_vertices)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    return seg_archive_core(c, true, dev_tracks, dev_quality, dev_count, cap_rows, out_vertices);
 }
 
 // ---- measurement -------------------------------------------------------------------------------

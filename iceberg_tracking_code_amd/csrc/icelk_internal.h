@@ -47,6 +47,7 @@ enum KernelId {
     K_EMIT,
     K_PROJECT,
     K_SYNTH,
+    K_LK_FB_PAIR,   // two segment pairs in one launch (icelk_seg_track_defer)
     K_COUNT_
 };
 
@@ -62,7 +63,9 @@ struct Slot {
     // last readers of the slot: pyramid/tracker launches on the compute stream, the corner kernel on the
     // detection stream.  An asynchronous upload into the slot waits for exactly these, not for everything that
     // happens to be queued, so frame t+1 crosses PCIe while frame t is being tracked.
-    hipEvent_t used = nullptr, det_used = nullptr;
+    // `used` refers to the event that covers the latest such launch: the slot's own (`used_own`) or one shared by
+    // everything a tracker launch touched (Ctx::launch_ev), so that a launch costs one event record, not one per slot
+    hipEvent_t used = nullptr, used_own = nullptr, det_used = nullptr;
     unsigned long long gen = 0;   // bumped whenever a new frame enters the slot
 };
 
@@ -78,7 +81,7 @@ void launch_bgr2gray(hipStream_t s, const uint8_t* src, int src_pitch, uint8_t* 
                      int w, int h, int variant);
 void launch_pyrdown(hipStream_t s, const Level& src, const Level& dst);
 // lv[first+1 .. first+n] (n = 1..3) from lv[first] in ONE launch (k_pyramid.hip)
-void launch_pyramid_fused(hipStream_t s, const Level* lv, int first, int n);
+void launch_pyramid_fused(hipStream_t s, const Level* lv, int first, int n, bool one_wave = false);
 void launch_synth(hipStream_t s, const Level& dst, int64_t ux, int64_t uy, uint32_t seed, const int* affine);
 
 // LK.  p_in/p_out etc. are device pointers.  fb = fused forward+backward.
@@ -111,9 +114,19 @@ struct LKBuffers {
     // measurement (icelk_prof_enable): LK iterations each feature ran, forward pass in the low half, backward in the high
     uint32_t* iters;
 };
+// one tracker job: a frame pair and the features tracked across it
+struct LKJob {
+    Pyramid I, J;
+    LKBuffers B;
+    int n;
+};
 size_t lk_lds_bytes(const LKParams& P);
 int launch_lk(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
               bool fb);
+// Two INDEPENDENT jobs with the same LK parameters in one launch (the last pair of a closing segment and the first pair
+// of the next one: s1:362,440 make them independent): ramp-up and tail of the launch are paid once for both.  Returns
+// false when no kernel for this window takes two jobs (the caller then launches them one after the other).
+bool launch_lk_pair(hipStream_t s, const LKJob& a, const LKJob& b, const LKParams& P);
 
 // Detector stages.
 struct DetectScratch {

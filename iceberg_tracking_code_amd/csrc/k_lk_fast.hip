@@ -223,12 +223,34 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
     return Rz;
 }
 
+// Up to two jobs per launch.  Workgroups are dealt to the jobs in groups of 8 (one group = one workgroup per XCD, so a
+// job keeps its XCD <-> contiguous-eighth mapping): groups alternate between the jobs while both have groups left, the
+// longer job takes the rest.  g0, g1 = workgroups of the two jobs (multiples of 8; g1 = 0: a single job).
+struct LKJobs {
+    LKJob job[2];
+    int g0, g1;
+};
+
 template <int WW, int WH, bool FB>
-__global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : (Cfg<WW, WH>::TPL == 2 ? 3 : 2))) void k_lk_fast(Pyramid PI, Pyramid PJ, LKBuffers B, int n, LKParams P)
+__global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : (Cfg<WW, WH>::TPL == 2 ? 3 : 2))) void k_lk_fast(LKJobs JJ, LKParams P)
 {
     using C = Cfg<WW, WH>;
     __shared__ uint32_t lds[C::LDS_DW];
-    const int f = launch_slot(B, blockIdx.x, B.n_dev ? *B.n_dev : n);
+    int which = 0, b = blockIdx.x;
+    if (JJ.g1 > 0) {
+        const int G = b >> 3, m = (JJ.g0 < JJ.g1 ? JJ.g0 : JJ.g1) >> 3;   // groups interleaved per job
+        if (G < 2 * m) {
+            which = G & 1;
+            b = ((G >> 1) << 3) | (b & 7);
+        } else {
+            which = JJ.g0 < JJ.g1 ? 1 : 0;
+            b = ((G - m) << 3) | (b & 7);
+        }
+    }
+    const LKJob& J = JJ.job[which];
+    const LKBuffers& B = J.B;
+    // the same for every lane (a table entry fetched by a vector load): keep it in a scalar register
+    const int f = __builtin_amdgcn_readfirstlane(launch_slot(B, b, B.n_dev ? *B.n_dev : J.n));
     if (f < 0) return;
     if (B.seg_alive && !B.seg_alive[f]) return;
     const int lane = threadIdx.x;
@@ -236,7 +258,7 @@ __global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : (Cfg<WW, WH>::TPL 
     uint32_t* ldsJ = lds + C::I_DW;
     const float p0x = B.p_in[2 * f], p0y = B.p_in[2 * f + 1];
     if (lane == 0) stamp(B, 0);
-    const TrackResult r1 = track_point_fast<WW, WH>(PI, PJ, p0x, p0y, P, ldsI, ldsJ, lane);
+    const TrackResult r1 = track_point_fast<WW, WH>(J.I, J.J, p0x, p0y, P, ldsI, ldsJ, lane);
     if (lane == 0) {
         if (B.p_fwd) { B.p_fwd[2 * f] = r1.x; B.p_fwd[2 * f + 1] = r1.y; }
         if (B.st_fwd) B.st_fwd[f] = (uint8_t)r1.status;
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : (Cfg<WW, WH>::TPL 
         if (B.iters && !FB) B.iters[f] = (uint32_t)r1.iters;
     }
     if (FB) {
-        const TrackResult r2 = track_point_fast<WW, WH>(PJ, PI, r1.x, r1.y, P, ldsI, ldsJ, lane);
+        const TrackResult r2 = track_point_fast<WW, WH>(J.J, J.I, r1.x, r1.y, P, ldsI, ldsJ, lane);
         if (lane == 0) {
             if (B.p_bwd) { B.p_bwd[2 * f] = r2.x; B.p_bwd[2 * f + 1] = r2.y; }
             if (B.st_bwd) B.st_bwd[f] = (uint8_t)r2.status;
@@ -259,12 +281,30 @@ __global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : (Cfg<WW, WH>::TPL 
     if (lane == 0) stamp(B, 1);
 }
 
+int grid_of(const LKBuffers& B, int n) { return B.order ? (n + 15) & ~7 : (n + 7) & ~7; }
+
 template <int WW, int WH>
-void launch_fast(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
-                 bool fb)
+void launch_fast(hipStream_t s, const LKJob& a, const LKJob* b, const LKParams& P, bool fb)
 {
-    if (fb) hipLaunchKernelGGL((k_lk_fast<WW, WH, true>), dim3(B.order ? (n + 15) & ~7 : n), dim3(64), 0, s, I, J, B, n, P);
-    else hipLaunchKernelGGL((k_lk_fast<WW, WH, false>), dim3(B.order ? (n + 15) & ~7 : n), dim3(64), 0, s, I, J, B, n, P);
+    LKJobs JJ;
+    JJ.job[0] = a;
+    JJ.job[1] = b ? *b : a;
+    JJ.g0 = grid_of(a.B, a.n);
+    JJ.g1 = b ? grid_of(b->B, b->n) : 0;
+    const int grid = JJ.g0 + JJ.g1;
+    if (fb) hipLaunchKernelGGL((k_lk_fast<WW, WH, true>), dim3(grid), dim3(64), 0, s, JJ, P);
+    else hipLaunchKernelGGL((k_lk_fast<WW, WH, false>), dim3(grid), dim3(64), 0, s, JJ, P);
+}
+
+bool dispatch_fast(hipStream_t s, const LKJob& a, const LKJob* b, const LKParams& P, bool fb)
+{
+    if (P.flags & ICELK_FLAG_INITIAL_FLOW) return false;
+    if (P.win_w == 21 && P.win_h == 21) launch_fast<21, 21>(s, a, b, P, fb);
+    else if (P.win_w == 31 && P.win_h == 31) launch_fast<31, 31>(s, a, b, P, fb);
+    else if (P.win_w == 35 && P.win_h == 35) launch_fast<35, 35>(s, a, b, P, fb);
+    else if (P.win_w == 15 && P.win_h == 15) launch_fast<15, 15>(s, a, b, P, fb);
+    else return false;
+    return true;
 }
 
 }  // namespace
@@ -273,13 +313,19 @@ void launch_fast(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuff
 bool launch_lk_fast(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,
                     bool fb)
 {
-    if (P.flags & ICELK_FLAG_INITIAL_FLOW) return false;
-    if (P.win_w == 21 && P.win_h == 21) launch_fast<21, 21>(s, I, J, B, n, P, fb);
-    else if (P.win_w == 31 && P.win_h == 31) launch_fast<31, 31>(s, I, J, B, n, P, fb);
-    else if (P.win_w == 35 && P.win_h == 35) launch_fast<35, 35>(s, I, J, B, n, P, fb);
-    else if (P.win_w == 15 && P.win_h == 15) launch_fast<15, 15>(s, I, J, B, n, P, fb);
-    else return false;
-    return true;
+    LKJob a;
+    a.I = I;
+    a.J = J;
+    a.B = B;
+    a.n = n;
+    return dispatch_fast(s, a, nullptr, P, fb);
+}
+
+bool launch_lk_pair(hipStream_t s, const LKJob& a, const LKJob& b, const LKParams& P)
+{
+    if (P.flags & (ICELK_FLAG_GENERIC_KERNEL | ICELK_FLAG_MULTI_PER_WAVE)) return false;
+    if (a.n <= 0 || b.n <= 0) return false;
+    return dispatch_fast(s, a, &b, P, true);
 }
 
 }  // namespace icelk

@@ -44,15 +44,22 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
-constexpr int T0 = 128;                        // owned level-0 tile
-// region origins relative to the tile origin of that level, and region sizes (columns are padded to dword multiples so
-// that the owned block starts on a dword)
-constexpr int L0_OX = -20, L0_OY = -14, L0_W = 156, L0_H = 149;   // needs [-18,134] x [-14,134]
-constexpr int L1_OX = -8, L1_OY = -6, L1_W = 76, L1_H = 73;       // needs [-6,66]: columns 2.. of the region
-constexpr int L2_OX = -4, L2_OY = -2, L2_W = 40, L2_H = 35;       // needs [-2,32]: columns 2.. of the region
-constexpr int L3_W = 16, L3_H = 16;
-constexpr int L0_BYTES = L0_W * L0_H, L1_BYTES = L1_W * L1_H, L2_BYTES = L2_W * L2_H, L3_BYTES = L3_W * L3_H;
-constexpr int LDS_BYTES = ((L0_BYTES + 15) & ~15) + ((L1_BYTES + 15) & ~15) + ((L2_BYTES + 15) & ~15) + L3_BYTES;
+// Geometry of a workgroup that owns a T0 x T0 tile of level 0 (T0 = 128 with 256 threads: 156 x 149 B region, 42 % halo;
+// T0 = 64 with ONE wave: 92 x 85, 91 % halo -- more bytes through L2 and more arithmetic, but a one-wave workgroup fits
+// into the slot a single retiring tracker wave leaves, so a pyramid built beside a tracker launch is not held up until
+// that launch has drained; a 4-wave workgroup never finds four free slots on one CU while the tracker has workgroups
+// pending).  Region origins are relative to the tile origin of that level; columns are padded to dword multiples so
+// that the owned block starts on a dword.
+template <int T0_, int NT_>
+struct Geo {
+    static constexpr int T0 = T0_, NT = NT_;
+    static constexpr int L0_OX = -20, L0_OY = -14, L0_W = T0 + 28, L0_H = T0 + 21;   // needs [-18,T0+6] x [-14,T0+6]
+    static constexpr int L1_OX = -8, L1_OY = -6, L1_W = T0 / 2 + 12, L1_H = T0 / 2 + 9;   // needs [-6,T0/2+2]: columns 2.. of the region
+    static constexpr int L2_OX = -4, L2_OY = -2, L2_W = T0 / 4 + 8, L2_H = T0 / 4 + 3;    // needs [-2,T0/4]: columns 2.. of the region
+    static constexpr int L3_W = T0 / 8, L3_H = T0 / 8;
+    static constexpr int L0_BYTES = L0_W * L0_H, L1_BYTES = L1_W * L1_H, L2_BYTES = L2_W * L2_H, L3_BYTES = L3_W * L3_H;
+    static constexpr int LDS_BYTES = ((L0_BYTES + 15) & ~15) + ((L1_BYTES + 15) & ~15) + ((L2_BYTES + 15) & ~15) + ((L3_BYTES + 15) & ~15);
+};
 
 struct LevelIO {
     uint8_t* ptr;
@@ -91,19 +98,19 @@ __device__ __forceinline__ void pyr_task(const uint8_t* __restrict__ src, int sp
 // One level of the tile: NCOL x ROWS outputs of the destination region (columns from column FIRST_COL of the region),
 // runs of CH rows per task; the ROWS % CH rows left over are tasks of their own (a run of CH with one live row would
 // cost as much as a full one).  Region index (ox, oy) <-> source region: column 2*ox + scol, row 2*oy.
-template <int CH, int NCOL, int ROWS, int FIRST_COL>
+template <int NT, int CH, int NCOL, int ROWS, int FIRST_COL>
 __device__ __forceinline__ void pyr_level(const uint8_t* __restrict__ src, int spitch, int scol, uint8_t* __restrict__ dst,
                                           int dpitch, int tid)
 {
     constexpr int NFULL = ROWS / CH, REM = ROWS - NFULL * CH;
-    for (int t = tid; t < NCOL * NFULL; t += 256) {
+    for (int t = tid; t < NCOL * NFULL; t += NT) {
         const int ch = t / NCOL;
         pyr_task<CH>(src, spitch, scol, dst, dpitch, FIRST_COL + (t - ch * NCOL), ch * CH);
     }
     if constexpr (REM > 0) {
         // the leftover rows: threads from the far end of the workgroup, so that they fall into the partly filled last
         // round of the loop above rather than into a round of their own
-        for (int t = 255 - tid; t < NCOL; t += 256) pyr_task<REM>(src, spitch, scol, dst, dpitch, FIRST_COL + t, NFULL * CH);
+        for (int t = NT - 1 - tid; t < NCOL; t += NT) pyr_task<REM>(src, spitch, scol, dst, dpitch, FIRST_COL + t, NFULL * CH);
     }
 }
 
@@ -111,17 +118,18 @@ __device__ __forceinline__ void pyr_level(const uint8_t* __restrict__ src, int s
 // reach) take the value of their mirror positions (BORDER_REFLECT_101), which the same region holds: first the four
 // columns -2, -1, w, w+1 over every row, then -- behind a barrier, so that the corners come out right -- the four rows
 // -2, -1, h, h+1 over every column.  (gx0, gy0) = global coordinates of region (0, 0).  A few hundred byte copies.
+template <int NT>
 __device__ __forceinline__ void fill_edges(uint8_t* __restrict__ reg, int pitch, int cols, int rows, int gx0, int gy0, int w,
                                            int h, int tid)
 {
-    for (int i = tid; i < 4 * rows; i += 256) {
+    for (int i = tid; i < 4 * rows; i += NT) {
         const int k = i & 3, r = i >> 2;
         const int gx = k < 2 ? k - 2 : w + (k - 2);
         const int c = gx - gx0, sc = reflect101(gx, w) - gx0;
         if ((unsigned)c < (unsigned)cols && (unsigned)sc < (unsigned)cols) reg[r * pitch + c] = reg[r * pitch + sc];
     }
     __syncthreads();
-    for (int i = tid; i < 4 * cols; i += 256) {
+    for (int i = tid; i < 4 * cols; i += NT) {
         const int k = i & 3, c = i >> 2;
         const int gy = k < 2 ? k - 2 : h + (k - 2);
         const int r = gy - gy0, sr = reflect101(gy, h) - gy0;
@@ -131,10 +139,11 @@ __device__ __forceinline__ void fill_edges(uint8_t* __restrict__ reg, int pitch,
 }
 
 // the owned block of a region goes to global memory as dwords: rows [ry, ry+rows) x byte columns [rx, rx + 4*dwords)
+template <int NT>
 __device__ __forceinline__ void copy_out(const uint8_t* __restrict__ reg, int rpitch, int rx, int ry, int rows, int dwords,
                                          const LevelIO& L, int gx0, int gy0, int tid)
 {
-    for (int i = tid; i < rows * dwords; i += 256) {
+    for (int i = tid; i < rows * dwords; i += NT) {
         const int r = i / dwords, c = i - r * dwords;
         const int gy = gy0 + r, gx = gx0 + 4 * c;
         if (gy < L.h && gx < L.w)   // a last dword may run into the row padding (pitch is a multiple of 64): harmless
@@ -143,16 +152,20 @@ __device__ __forceinline__ void copy_out(const uint8_t* __restrict__ reg, int rp
     }
 }
 
-template <int NL>
-__global__ __launch_bounds__(256) void k_pyramid(LevelIO S, LevelIO D1, LevelIO D2, LevelIO D3, unsigned long long* stamps)
+template <int NL, int T0, int NT>
+__global__ __launch_bounds__(NT) void k_pyramid(LevelIO S, LevelIO D1, LevelIO D2, LevelIO D3, unsigned long long* stamps)
 {
 #define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[8 * (blockIdx.y * gridDim.x + blockIdx.x) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     STAMP(0);
-    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+    using G = Geo<T0, NT>;
+    constexpr int L0_OX = G::L0_OX, L0_OY = G::L0_OY, L0_W = G::L0_W, L0_H = G::L0_H, L1_OX = G::L1_OX, L1_OY = G::L1_OY,
+                  L1_W = G::L1_W, L1_H = G::L1_H, L2_OX = G::L2_OX, L2_OY = G::L2_OY, L2_W = G::L2_W, L2_H = G::L2_H,
+                  L3_W = G::L3_W, L3_H = G::L3_H;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[G::LDS_BYTES];
     uint8_t* R0 = lds;
-    uint8_t* R1 = R0 + ((L0_BYTES + 15) & ~15);
-    uint8_t* R2 = R1 + ((L1_BYTES + 15) & ~15);
-    uint8_t* R3 = R2 + ((L2_BYTES + 15) & ~15);
+    uint8_t* R1 = R0 + ((G::L0_BYTES + 15) & ~15);
+    uint8_t* R2 = R1 + ((G::L1_BYTES + 15) & ~15);
+    uint8_t* R3 = R2 + ((G::L2_BYTES + 15) & ~15);
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * T0, y0 = blockIdx.y * T0;          // level-0 tile origin
     const int x1 = x0 / 2, y1 = y0 / 2, x2 = x0 / 4, y2 = y0 / 4, x3 = x0 / 8, y3 = y0 / 8;
@@ -166,12 +179,12 @@ __global__ __launch_bounds__(256) void k_pyramid(LevelIO S, LevelIO D1, LevelIO 
     // (pitch is a multiple of 64), bytes the edge fill below overwrites or nothing ever looks at.  No byte path, no
     // branch: every load of the thread is in flight before the first LDS write waits for one.
     {
-        constexpr int NDW = L0_W / 4, N = (NDW * L0_H + 255) / 256;
+        constexpr int NDW = L0_W / 4, N = (NDW * L0_H + NT - 1) / NT;
         uint32_t v[N];
         const int gx0 = x0 + L0_OX, gy0 = y0 + L0_OY;
 #pragma unroll
         for (int m = 0; m < N; m++) {
-            const int i = tid + 256 * m;
+            const int i = tid + NT * m;
             const int r = i / NDW, c = i - r * NDW;
             const int gy = gy0 + r, gx = gx0 + 4 * c;
             const bool ok = i < NDW * L0_H && (unsigned)gy < (unsigned)S.h && (unsigned)gx < (unsigned)S.w;
@@ -180,32 +193,32 @@ __global__ __launch_bounds__(256) void k_pyramid(LevelIO S, LevelIO D1, LevelIO 
         }
 #pragma unroll
         for (int m = 0; m < N; m++) {
-            const int i = tid + 256 * m;
+            const int i = tid + NT * m;
             if (i < NDW * L0_H) reinterpret_cast<uint32_t*>(R0)[i] = v[m];
         }
     }
     __syncthreads();
-    if (!interior) fill_edges(R0, L0_W, L0_W, L0_H, x0 + L0_OX, y0 + L0_OY, S.w, S.h, tid);
+    if (!interior) fill_edges<NT>(R0, L0_W, L0_W, L0_H, x0 + L0_OX, y0 + L0_OY, S.w, S.h, tid);
     STAMP(1);
 
-    // ---- stages 2-4: level 1 (region columns 2 .. 74, rows 0 .. 72), level 2 (columns 2 .. 36, rows 0 .. 34), level 3 ----
+    // ---- stages 2-4: level 1 (region columns 2 .. W-2, every row), level 2 (columns 2 .. T0/4+4), level 3 ----
     // region index (ox, oy) of a level <-> source region: column 2*ox + scol, row 2*oy, with scol = +2, -2, +2
-    pyr_level<8, L1_W - 3, L1_H, 2>(R0, L0_W, 2, R1, L1_W, tid);
+    pyr_level<NT, 8, L1_W - 3, L1_H, 2>(R0, L0_W, 2, R1, L1_W, tid);
     __syncthreads();
     STAMP(2);
-    copy_out(R1, L1_W, -L1_OX, -L1_OY, T0 / 2, T0 / 8, D1, x1, y1, tid);
+    copy_out<NT>(R1, L1_W, -L1_OX, -L1_OY, T0 / 2, T0 / 8, D1, x1, y1, tid);
     STAMP(3);
     if (NL == 1) return;
-    if (!interior) fill_edges(R1, L1_W, L1_W, L1_H, x1 + L1_OX, y1 + L1_OY, D1.w, D1.h, tid);
-    pyr_level<8, 35, L2_H, 2>(R1, L1_W, -2, R2, L2_W, tid);
+    if (!interior) fill_edges<NT>(R1, L1_W, L1_W, L1_H, x1 + L1_OX, y1 + L1_OY, D1.w, D1.h, tid);
+    pyr_level<NT, 8, L2_W - 5, L2_H, 2>(R1, L1_W, -2, R2, L2_W, tid);
     __syncthreads();
     STAMP(4);
-    copy_out(R2, L2_W, -L2_OX, -L2_OY, T0 / 4, T0 / 16, D2, x2, y2, tid);
+    copy_out<NT>(R2, L2_W, -L2_OX, -L2_OY, T0 / 4, T0 / 16, D2, x2, y2, tid);
     if (NL == 2) return;
-    if (!interior) fill_edges(R2, L2_W, L2_W, L2_H, x2 + L2_OX, y2 + L2_OY, D2.w, D2.h, tid);
-    pyr_level<2, L3_W, L3_H, 0>(R2, L2_W, 2, R3, L3_W, tid);
+    if (!interior) fill_edges<NT>(R2, L2_W, L2_W, L2_H, x2 + L2_OX, y2 + L2_OY, D2.w, D2.h, tid);
+    pyr_level<NT, 2, L3_W, L3_H, 0>(R2, L2_W, 2, R3, L3_W, tid);
     __syncthreads();
-    copy_out(R3, L3_W, 0, 0, T0 / 8, T0 / 32, D3, x3, y3, tid);
+    copy_out<NT>(R3, L3_W, 0, 0, T0 / 8, T0 / 32, D3, x3, y3, tid);
     STAMP(5);
 }
 
@@ -221,8 +234,8 @@ LevelIO io_of(const Level& L)
 
 }  // namespace
 
-// Builds lv[first+1 .. first+n] (n = 1..3) from lv[first] in one launch.
-void launch_pyramid_fused(hipStream_t s, const Level* lv, int first, int n)
+template <int T0, int NT>
+static void launch_geo(hipStream_t s, const Level* lv, int first, int n)
 {
     const Level& S = lv[first];
     dim3 grid((S.w + T0 - 1) / T0, (S.h + T0 - 1) / T0);
@@ -233,15 +246,23 @@ void launch_pyramid_fused(hipStream_t s, const Level* lv, int first, int n)
     static const char* st_path = getenv("ICELK_PYR_STAMPS");
     const size_t nst = 8 * (size_t)grid.x * grid.y;
     if (st_path && !d_st) hipMalloc(reinterpret_cast<void**>(&d_st), 8 * 8 * 65536);
-    if (n == 1) hipLaunchKernelGGL(k_pyramid<1>, grid, dim3(256), 0, s, src, d1, d2, d3, d_st);
-    else if (n == 2) hipLaunchKernelGGL(k_pyramid<2>, grid, dim3(256), 0, s, src, d1, d2, d3, d_st);
-    else hipLaunchKernelGGL(k_pyramid<3>, grid, dim3(256), 0, s, src, d1, d2, d3, d_st);
+    if (n == 1) hipLaunchKernelGGL((k_pyramid<1, T0, NT>), grid, dim3(NT), 0, s, src, d1, d2, d3, d_st);
+    else if (n == 2) hipLaunchKernelGGL((k_pyramid<2, T0, NT>), grid, dim3(NT), 0, s, src, d1, d2, d3, d_st);
+    else hipLaunchKernelGGL((k_pyramid<3, T0, NT>), grid, dim3(NT), 0, s, src, d1, d2, d3, d_st);
     if (d_st && nst <= 8 * 65536) {
         std::vector<unsigned long long> hst(nst);
         hipStreamSynchronize(s);
         hipMemcpy(hst.data(), d_st, nst * 8, hipMemcpyDeviceToHost);
         if (FILE* f = fopen(st_path, "wb")) { fwrite(hst.data(), 8, nst, f); fclose(f); }
     }
+}
+
+// Builds lv[first+1 .. first+n] (n = 1..3) from lv[first] in one launch.  `one_wave`: the 64 x 64 / one-wave geometry,
+// for a pyramid that is built beside a tracker launch (see Geo).
+void launch_pyramid_fused(hipStream_t s, const Level* lv, int first, int n, bool one_wave)
+{
+    if (one_wave) launch_geo<64, 64>(s, lv, first, n);
+    else launch_geo<128, 256>(s, lv, first, n);
 }
 
 }  // namespace icelk

@@ -152,7 +152,8 @@ class SegmentTracker:
     """
 
     def __init__(self, width, height, track_len, feature_params=None, lk_params=None, mask=None, max_pts=1 << 18,
-                 device=0, fb_threshold=REF_FB_THRESHOLD, ctx=None, n_slots=3, lookahead=True, mask_polygon=None):
+                 device=0, fb_threshold=REF_FB_THRESHOLD, ctx=None, n_slots=3, lookahead=True, mask_polygon=None,
+                 pair_launch=True):
         self.track_len = int(track_len)
         if self.track_len < 1 or self.track_len > 16:
             raise ValueError("track_len must be in 1..16")
@@ -176,12 +177,22 @@ class SegmentTracker:
         self.n_detected = 0
         self._prefetched = []     # slots holding frames whose upload was started ahead of time
         self.lookahead = bool(lookahead)
-        self._pyr_ahead = None    # slot whose pyramid was enqueued ahead of its step
+        self.pair_launch = bool(pair_launch) and self.lookahead   # see `_step`: joint launch across a segment change
+        self._pyr_ahead = set()   # slots whose pyramid was enqueued ahead of their step
+        # how many steps ahead of a detection frame its min-distance stage / its corner candidates may start (`_step`)
+        self.begin_ahead, self.prepare_ahead = [int(v) for v in os.environ.get("ICELK_DET_AHEAD", "3,4").split(",")]
         self._resident = False    # inside push_slot
-        self.on_close = None      # callable(first_frame) invoked when a segment closes, before the switch to the next
+        # callable(first_frame, closed) invoked once per finished segment, when all its pairs have been launched: e.g.
+        # ctx.seg_archive(..., closed=closed).  closed=False: the segment is still the current one (the switch follows);
+        # closed=True: the switch has happened (its last pair went out in a joint launch, see `_step`)
+        self.on_close = None
+        self._advanced = False    # the pair (cur, next) has gone out already, with the joint launch of this step
         self._det_for = None      # frame counter whose detection (min-distance stage) is in flight
-        self._prepared_for = None  # frame counter whose corner candidates have been prepared ahead
+        self._det_begun = -1      # ... and the step at which it was begun
+        self._begun_upto = -1     # latest frame whose detection has been begun
+        self._prep_upto = -1      # latest frame whose corner candidates have been prepared ahead
         self._staged = False      # a new segment waits in the spare set for the switch
+        self._staged_for = None   # ... the detection frame it belongs to
         self._staged_n = 0
 
     # -- frame sources --------------------------------------------------------------------------
@@ -227,16 +238,16 @@ class SegmentTracker:
             raise RuntimeError("no prefetched frame")
         s = self._prefetched.pop(0)
         q = self._prefetched
-        return self._step(s, wait, q[0] if q else None, q[1] if len(q) > 1 else None, q[2] if len(q) > 2 else None)
+        return self._step(s, wait, *[q[k] if len(q) > k else None for k in range(4)])
 
-    def push_slot(self, slot, wait=True, next_slot=None, next2_slot=None, next3_slot=None):
+    def push_slot(self, slot, wait=True, next_slot=None, next2_slot=None, next3_slot=None, next4_slot=None):
         """Use a frame that already sits in `slot` (level 0 resident in HBM); its pyramid is rebuilt.
-        `next_slot`, `next2_slot`, `next3_slot`: where the following frames already sit, if they do (see `_step`)."""
-        if self._pyr_ahead != slot:
+        `next_slot` .. `next4_slot`: where the following frames already sit, if they do (see `_step`)."""
+        if slot not in self._pyr_ahead:
             self.ctx.drop_pyramid(slot)
         self._resident = True
         try:
-            return self._step(slot, wait, next_slot, next2_slot, next3_slot)
+            return self._step(slot, wait, next_slot, next2_slot, next3_slot, next4_slot)
         finally:
             self._resident = False
 
@@ -250,16 +261,25 @@ class SegmentTracker:
         self.ctx.seg_detect_begin(slot, self.fp["maxCorners"], self.fp["qualityLevel"], self.fp["minDistance"],
                                   self.use_mask, self.fp.get("blockSize", 3))
 
-    def _step(self, slot, wait, next_slot=None, next2_slot=None, next3_slot=None):
-        """One pass of the loop body.  `next_slot` / `next2_slot` / `next3_slot`: slots of the FOLLOWING frames when they
-        are already on their way to the device (prefetched uploads, resident ring).  The detector needs nothing but its
-        own frame, so the work for a coming detection frame c is spread over the steps before it and runs beside their
-        tracker launches: corner candidates at step c-3 (`seg_detect_prepare`, spare buffer, own stream), min-distance
-        stage at c-2 (`seg_detect_begin`), and at c-1 the one host round trip of a detection, the sort and the new
-        segment's initialisation in the spare set of segment buffers (`seg_detect_stage`).  At step c only the switch is
-        left (no GPU work, no wait), so the tracker launch of frame c+1 never waits for the host.  With less lookahead
-        the same calls move later (candidates c-2, min-distance c-1, stage + switch at c); with none, everything
-        happens at c.  Results are those of the serial order either way."""
+    def _step(self, slot, wait, next_slot=None, next2_slot=None, next3_slot=None, next4_slot=None):
+        """One pass of the loop body.  `next_slot` .. `next4_slot`: slots of the FOLLOWING frames when they are already
+        on their way to the device (prefetched uploads, resident ring).  The detector needs nothing but its own frame,
+        so the work for a coming detection frame d is spread over the steps before it and runs beside their tracker
+        launches, each part as early as the frame's slot is known and the buffers it needs are free:
+          d-4  corner candidates (`seg_detect_prepare`: spare candidate buffer, own stream)
+          d-3  min-distance stage (`seg_detect_begin`)
+          d-2  the one host round trip of a detection, the sort and the new segment's initialisation in the spare set
+               of segment buffers (`seg_detect_stage`) -- issued BEHIND the tracker launch of that step, and waiting
+               for kernels that had a whole step to finish: the host never stands between two tracker launches
+          d    the switch (no GPU work, no wait).
+        With less lookahead the same calls move later, each at least one step after the one before; with none,
+        everything happens at d.
+
+        Joint launch: the last pair of the closing segment, (d-1, d), and the first pair of the new one, (d, d+1), are
+        independent (s1:362 / s1:440).  When frame d+1 is already on the device and nothing has to be read at d, step d
+        holds the first back (`seg_track_defer`), switches, and tracks (d, d+1) at once: both pairs go to the device as
+        ONE tracker launch and step d+1 has no pair left to launch.  Results are those of the serial order in every
+        case."""
         out = None
         prev = self.cur
         T = self.track_len
@@ -267,41 +287,50 @@ class SegmentTracker:
         detect = c % T == 0
         ahead = self.lookahead and T >= 2
         bs = self.fp.get("blockSize", 3)
-        # corner candidates of a coming detection frame, as early as its slot is known (three steps ahead at most)
-        if ahead:
-            for k, s_k in ((3, next3_slot), (2, next2_slot)):
-                if s_k is not None and (c + k) % T == 0 and self._prepared_for != c + k:
-                    self.ctx.seg_detect_prepare(s_k, self.use_mask, bs)
-                    self._prepared_for = c + k
-                    break
-        if detect and self._det_for != c and not self._staged:
+        lk_tail = (self.lk["winSize"], self.lk["maxLevel"], self.lk["criteria"], self.lk.get("minEigThreshold", 1e-4),
+                   self.fb_threshold)
+        slot_of = {0: slot, 1: next_slot, 2: next2_slot, 3: next3_slot, 4: next4_slot}
+        self._pyr_ahead.discard(slot)
+        staged_now = self._staged and self._staged_for == c
+        if detect and not staged_now and self._det_for != c:
             # nothing was started ahead for this detection frame: start it now, on its own stream, so that it runs
             # beside the tracker launch below (the reference does them back to back, s1:323-326 then s1:437)
             self._detect_begin(slot)
-            self._det_for = c
-        if self.active:
-            self.ctx.seg_track(prev, slot, self.lk["winSize"], self.lk["maxLevel"], self.lk["criteria"],
-                               self.lk.get("minEigThreshold", 1e-4), self.fb_threshold, wait=False)
-        self._pyr_ahead = None
-        if self.lookahead and next_slot is not None:
-            # the pyramid of the following frame, on the copy stream, in the shadow of the tracker launch above
-            if self._resident:
-                self.ctx.drop_pyramid(next_slot)   # a resident ring is rebuilt on every visit
-            self.ctx.build_pyramid_ahead(next_slot, self.lk["winSize"], self.lk["maxLevel"])
-            self._pyr_ahead = next_slot
-        if not detect and self._det_for == c + 1:
-            # the detection of the NEXT frame is in flight: take its host round trip now and build the new segment in
-            # the spare set, beside the segment that is still being tracked
-            self._staged_n = self.ctx.seg_detect_stage(self.fp["maxCorners"])
-            self._staged = True
-            self._det_for = None
-        if detect:
+            self._det_for, self._det_begun, self._begun_upto = c, c, c
+        joint = False
+        if self._advanced:
+            self._advanced = False            # the pair (prev, slot) went out with the launch of the previous step
+        elif self.active:
+            joint = detect and self.pair_launch and not wait and staged_now and next_slot is not None and c > 0
+            if joint:
+                self.ctx.seg_track_defer(prev, slot, *lk_tail)
+                self.ctx.seg_switch()
+                self.ctx.seg_track(slot, next_slot, *lk_tail, wait=False)
+                self._advanced = True
+                if self.on_close is not None:
+                    self.on_close(self.seg_first, True)
+                self.n_detected = self._staged_n
+                self._staged = False
+                self.seg_first = c
+            else:
+                self.ctx.seg_track(prev, slot, *lk_tail, wait=False)
+        if self.lookahead:
+            # pyramids of the following frames, on the copy stream, in the shadow of the tracker launch above (two ahead
+            # when a joint launch may need frame c+2 at step c+1)
+            for s_k in (next_slot, next2_slot if self.pair_launch else None):
+                if s_k is None or s_k in self._pyr_ahead or s_k in (slot, prev) or (s_k == next_slot and self._advanced):
+                    continue
+                if self._resident:
+                    self.ctx.drop_pyramid(s_k)   # a resident ring is rebuilt on every visit
+                self.ctx.build_pyramid_ahead(s_k, self.lk["winSize"], self.lk["maxLevel"])
+                self._pyr_ahead.add(s_k)
+        if detect and not joint:
             if c > 0 and self.on_close is not None:
-                self.on_close(self.seg_first)     # e.g. ctx.seg_archive(...) of the closing segment, still current here
+                self.on_close(self.seg_first, False)
             if c > 0 and wait:
                 tracks, quality = self.ctx.seg_read()
                 out = (self.seg_first, tracks, quality)
-            if self._staged:
+            if staged_now:
                 self.ctx.seg_switch()
                 self.n_detected = self._staged_n
                 self._staged = False
@@ -310,17 +339,34 @@ class SegmentTracker:
                 self._det_for = None
             self.active = True
             self.seg_first = c
-        # min-distance stage of a coming detection frame: two steps ahead when its slot is known, else one step ahead
-        # (behind the tracker launch of this step in issue order: the launch on the critical path goes out first)
-        if ahead and self._det_for is None and not self._staged:
-            for k, s_k in ((2, next2_slot), (1, next_slot)):
-                if s_k is not None and (c + k) % T == 0:
-                    self._detect_begin(s_k)
-                    self._det_for = c + k
-                    break
+        if ahead:
+            # corner candidates of the detection frame after the one begun last, up to four steps ahead, once the spare
+            # candidate buffer is free (the candidates prepared before have been adopted by their seg_detect_begin);
+            # first, so that the kernel is on the device before the host waits below
+            d = max(self._begun_upto, self._prep_upto, c) // T * T + T
+            if self._prep_upto <= self._begun_upto and 1 <= d - c <= self.prepare_ahead and slot_of[d - c] is not None:
+                self.ctx.seg_detect_prepare(slot_of[d - c], self.use_mask, bs)
+                self._prep_upto = d
+            # the detection in flight, begun at an earlier step: its host round trip, and the new segment into the spare
+            # set (behind this step's switch, if there was one: the spare set is the one after the current)
+            if self._det_for is not None and self._det_for > c and self._det_begun < c and not self._staged:
+                self._staged_n = self.ctx.seg_detect_stage(self.fp["maxCorners"])
+                self._staged, self._staged_for = True, self._det_for
+                self._det_for = None
+            # min-distance stage of the next detection frame, up to three steps ahead
+            d = (self._begun_upto // T + 1) * T if self._begun_upto >= 0 else 0
+            d = max(d, (c // T + 1) * T)
+            if self._det_for is None and 1 <= d - c <= self.begin_ahead and slot_of[d - c] is not None:
+                self._detect_begin(slot_of[d - c])
+                self._det_for, self._det_begun, self._begun_upto = d, c, d
         self.cur = slot
         self.counter += 1
         return out
+
+    def flush(self):
+        """Nothing of a pushed frame is held back across steps any more; kept so that callers can mark the end of a
+        sequence (a pair waiting inside the library -- icelk_seg_track_defer used directly -- goes out)."""
+        self.ctx.seg_flush()
 
     def live(self):
         return self.ctx.seg_live()

@@ -197,6 +197,24 @@ int icelk_seg_read(icelk_t* h, float* tracks, float* quality, int cap, int max_v
  * buffers hold, must be >= the tracks the segment started with.  Enqueued on the handle's compute stream: no wait, no
  * host read-back. */
 int icelk_seg_archive(icelk_t* h, void* dev_tracks, void* dev_quality, void* dev_count, int cap_rows, int* out_vertices);
+/* The LAST pair of a segment and the FIRST pair of the next one are independent (s1:362 tracks the old features across
+ * (c-1, c), s1:440 starts the new segment from the corners of frame c, tracked across (c, c+1) one loop pass later).
+ * icelk_seg_track_defer takes the arguments of icelk_seg_track_async but launches nothing: the pair waits, and the next
+ * icelk_seg_track_async / _defer after icelk_seg_switch sends both pairs to the device as ONE tracker launch (ramp-up
+ * and tail of the launch are paid once; every workgroup still tracks one feature exactly as before).  The waiting pair
+ * goes out on its own whenever its result or its frames are needed first: icelk_seg_flush, icelk_sync, a read-out of
+ * its segment, a second switch, or an ingest / icelk_drop_pyramid into one of its two slots; also when the partner's
+ * LK parameters differ.  Results are those of icelk_seg_track_async in every case.
+ * After icelk_seg_switch the segment it closed stays addressable until the switch after: the _closed forms of the
+ * read-outs gather from it (and launch its waiting pair first if it still waits). */
+int icelk_seg_track_defer(icelk_t* h, int slot_prev, int slot_next, int win_w, int win_h, int max_level,
+                          int crit_type, int max_count, double epsilon, double min_eig_threshold,
+                          float fb_threshold);
+int icelk_seg_flush(icelk_t* h);
+int icelk_seg_read_closed(icelk_t* h, float* tracks, float* quality, int cap, int max_vertices, int* out_n,
+                          int* out_vertices);
+int icelk_seg_archive_closed(icelk_t* h, void* dev_tracks, void* dev_quality, void* dev_count, int cap_rows,
+                             int* out_vertices);
 /* non-blocking variants for pipelined loops: no host read-back, counts stay on the device */
 int icelk_seg_track_async(icelk_t* h, int slot_prev, int slot_next, int win_w, int win_h, int max_level,
                           int crit_type, int max_count, double epsilon, double min_eig_threshold,

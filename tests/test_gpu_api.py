@@ -149,11 +149,11 @@ def test_prefetched_uploads_equal_blocking_upload(synth, track_len):
 
 
 @pytest.mark.parametrize("track_len", [2, 3, 4])
-@pytest.mark.parametrize("depth", [1, 2, 3])
+@pytest.mark.parametrize("depth", [1, 2, 3, 4])
 def test_resident_ring_with_lookahead_equals_serial_loop(synth, track_len, depth):
-    """Frames resident in HBM (bench.py's source): with the next 1, 2 or 3 slots known, the work of a coming detection
-    frame moves ahead of it (candidates c-3, min-distance c-2, the host round trip + the new segment's initialisation in
-    the spare segment set at c-1, only the switch at c).  The segments -- read out at every detection frame -- must be
+    """Frames resident in HBM (bench.py's source): with the next 1 .. 4 slots known, the work of a coming detection
+    frame moves ahead of it (candidates c-4, min-distance c-3, the host round trip + the new segment's initialisation in
+    the spare segment set at c-2, only the switch at c).  The segments -- read out at every detection frame -- must be
     those of the loop that does everything at frame c."""
     from iceberg_tracking_code_amd import Context, SegmentTracker
     w, h, n = 640, 360, 14
@@ -169,8 +169,8 @@ def test_resident_ring_with_lookahead_equals_serial_loop(synth, track_len, depth
     trk = SegmentTracker(w, h, track_len, fp, lk, ctx=ctx)
     got = []
     for i in range(n):
-        nxt = [i + k if (i + k < n and k <= depth) else None for k in (1, 2, 3)]
-        s = trk.push_slot(i, wait=True, next_slot=nxt[0], next2_slot=nxt[1], next3_slot=nxt[2])
+        nxt = [i + k if (i + k < n and k <= depth) else None for k in (1, 2, 3, 4)]
+        s = trk.push_slot(i, True, *nxt)
         if s is not None:
             got.append(s)
     n_live, _ = trk.live()
@@ -179,6 +179,121 @@ def test_resident_ring_with_lookahead_equals_serial_loop(synth, track_len, depth
     for (fa, ta, qa), (fb, tb, qb) in zip(want, got):
         assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb) and len(ta) > 150
         assert ta.shape[1] == track_len + 1
+
+
+def _serial_segments(frames, w, h, track_len, fp, lk):
+    from iceberg_tracking_code_amd import SegmentTracker
+    ref = SegmentTracker(w, h, track_len, fp, lk, max_pts=4096, lookahead=False)
+    want = [s for s in (ref.push(f) for f in frames) if s is not None]
+    ref.close()
+    return want
+
+
+@pytest.mark.parametrize("source", ["resident", "push", "prefetch"])
+@pytest.mark.parametrize("track_len", [1, 2, 3])
+def test_joint_launch_across_segment_change_equals_serial_loop(synth, track_len, source):
+    """With no read-out at the detection frame (wait=False) and the following frame already on the device, the last
+    pair of a segment and the first pair of the next go out as ONE tracker launch (icelk_seg_track_defer + switch +
+    icelk_seg_track_async in one step); finished segments are reported through on_close and read with the _closed form.
+    Segments must be those of the serial loop, whatever the frame source: resident slots, uploads started ahead, and
+    plain uploads (where the following frame is not known and every pair has a launch of its own)."""
+    from iceberg_tracking_code_amd import Context, SegmentTracker
+    w, h, n = 640, 360, 12
+    frames, _ = synth.sequence(w, h, n, seed=35, max_step_px=2.0)
+    fp = dict(maxCorners=300, qualityLevel=0.007, minDistance=10, blockSize=10)
+    lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
+    want = _serial_segments(frames, w, h, track_len, fp, lk)
+    ctx = Context(w, h, n_slots={"resident": n, "push": 3, "prefetch": 5}[source], max_pts=4096)
+    trk = SegmentTracker(w, h, track_len, fp, lk, ctx=ctx)
+    got = []
+
+    def on_close(first, closed):
+        t, q = ctx.seg_read(closed=closed)
+        got.append((first, t, q, closed))
+    trk.on_close = on_close
+    ctx.prof_enable(True)
+    if source == "resident":
+        for i, f in enumerate(frames):
+            ctx.upload_gray(i, f)
+        for i in range(n):
+            nxt = [i + k if i + k < n else None for k in (1, 2, 3, 4)]
+            assert trk.push_slot(i, False, *nxt) is None
+    elif source == "push":
+        for f in frames:
+            assert trk.push(f, wait=False) is None
+    else:
+        ptrs = []
+        for f in frames:
+            p = ctx.host_alloc(w * h)
+            C.memmove(p, f.ctypes.data, w * h)
+            ptrs.append(p)
+        trk.prefetch_pinned(ptrs[0], w)
+        trk.prefetch_pinned(ptrs[1], w)
+        for i in range(n):
+            if i + 2 < n:
+                trk.prefetch_pinned(ptrs[i + 2], w)
+            assert trk.push_prefetched(wait=False) is None
+    trk.flush()
+    ctx.sync()
+    prof = ctx.prof_table()
+    if source == "prefetch":
+        for p in ptrs:
+            ctx.host_free(p)
+    trk.close()
+    n_pairs = n - 1
+    joint = prof.get("lk_fb_pair", {}).get("launches", 0)
+    single = prof.get("lk_fb", {}).get("launches", 0)
+    assert single + 2 * joint == n_pairs
+    if source == "push" or track_len == 1:
+        assert joint == 0
+    else:
+        assert joint >= (n_pairs // track_len) - 2 and any(g[3] for g in got)
+    assert len(got) == len(want) == (n - 1) // track_len
+    for (fa, ta, qa), (fb, tb, qb, _) in zip(want, got):
+        assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb) and len(ta) > 150
+        assert ta.shape[1] == track_len + 1
+
+
+def test_waiting_pair_goes_out_when_its_result_is_needed(synth):
+    """icelk_seg_track_defer launches nothing; icelk_seg_read of that segment, icelk_sync, an upload into one of the
+    pair's slots or a second switch launch the waiting pair first.  Each way gives the tracks of icelk_seg_track."""
+    from iceberg_tracking_code_amd import Context
+    w, h = 640, 360
+    frames, _ = synth.sequence(w, h, 4, seed=36, max_step_px=2.0)
+    det = (300, 0.007, 10, False, 10)
+    lk = ((21, 21), 3, (3, 30, 0.01), 1e-4, 1.0)
+    ctx = Context(w, h, n_slots=4, max_pts=4096)
+    for i, f in enumerate(frames):
+        ctx.upload_gray(i, f)
+    ctx.seg_detect(0, *det)
+    ctx.seg_track(0, 1, *lk)
+    want_t, want_q = ctx.seg_read()
+    ctx.prof_enable(True)
+    for how in ("read", "sync", "upload", "closed_read", "second_switch"):
+        ctx.prof_reset()
+        ctx.seg_detect(0, *det)
+        ctx.seg_track_defer(0, 1, *lk)
+        if how == "sync":
+            ctx.sync()
+        launches = lambda: ctx.prof_table().get("lk_fb", {}).get("launches", 0)
+        assert launches() == (1 if how == "sync" else 0)
+        closed = False
+        if how == "upload":
+            ctx.upload_gray(1, frames[3])       # the pair reads slot 1: it must run before the frame is replaced
+            ctx.upload_gray(1, frames[1])
+            assert launches() == 1
+        elif how in ("closed_read", "second_switch"):
+            ctx.seg_detect(1, *det)             # first switch: the pair keeps waiting, its segment is the closed one
+            assert launches() == 0
+            closed = True
+            if how == "second_switch":
+                ctx.seg_detect(2, *det)         # no partner came: the pair goes out; its segment is out of reach now
+                assert launches() == 1
+                continue
+        t, q = ctx.seg_read(closed=closed)
+        assert launches() == 1
+        assert np.array_equal(t, want_t) and np.array_equal(q, want_q) and len(t) > 150
+    ctx.close()
 
 
 def test_launch_order_is_invisible(synth, monkeypatch):

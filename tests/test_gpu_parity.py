@@ -24,12 +24,16 @@ def test_gray(ctx, orc, w, h, variant):
 
 @pytest.mark.parametrize("w,h", [(640, 480), (641, 479), (333, 257), (64, 48), (23, 31), (100, 8), (1023, 767), (129, 257),
                                  (128, 128), (127, 385), (1000, 3), (1, 70)])
-def test_pyramid(ctx, orc, synth, w, h):
+@pytest.mark.parametrize("ahead", [False, True])
+def test_pyramid(ctx, orc, synth, w, h, ahead):
     """All levels, bit for bit: the one-launch kernel (three levels per launch, tiles with recomputed halos, reflection
-    at every level's own border) -- sizes around the 128-px tile, odd sizes, levels narrower than a halo."""
+    at every level's own border) -- sizes around the tile, odd sizes, levels narrower than a halo.  `ahead`: built on
+    the copy stream (icelk_build_pyramid_ahead), where the one-wave geometry (64-px tiles) is used."""
     rng = np.random.RandomState(w + 13 * h)
     img = rng.randint(0, 256, size=(h, w)).astype(np.uint8)
     ctx.upload_gray(0, img)
+    if ahead:
+        ctx.build_pyramid_ahead(0, (5, 5), 6)
     top = ctx.build_pyramid(0, (5, 5), 6)
     ref = orc.build_pyramid(img, (5, 5), 6)
     assert top == len(ref) - 1

@@ -9,8 +9,12 @@ ctx = Context(w, h, n_slots=4, max_pts=1024)
 for i in range(4):
     ctx.synth_frame(i, w, h, 100 * i, -50 * i, 1234)
 ctx.sync()
+ahead = os.environ.get("PYR_AHEAD") == "1"     # the copy-stream path (one-wave geometry unless ICELK_PYR_AHEAD_WIDE=1)
 for rep in range(30):
     ctx.drop_pyramid(rep % 4)
-    ctx.build_pyramid(rep % 4, (21, 21), ml)
+    if ahead:
+        ctx.build_pyramid_ahead(rep % 4, (21, 21), ml)
+    else:
+        ctx.build_pyramid(rep % 4, (21, 21), ml)
 ctx.sync()
 ctx.close()

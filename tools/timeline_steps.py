@@ -10,7 +10,7 @@ def short(n):
 lk = [i for i, r in enumerate(rows) if "k_lk" in r[2]]
 if len(lk) < 16:
     print("too few tracker launches", len(lk)); sys.exit(0)
-a, b = lk[-9], lk[-5]      # four tracker launches = two steps of two
+a, b = lk[-7], lk[-4]      # three tracker launches
 t0 = rows[a][0]
 for s, e, n, q in rows[a:b + 1]:
     print("%9.1f %8.1f  q%-3s %s" % ((s - t0) / 1e3, (e - s) / 1e3, q[-3:], short(n)))
