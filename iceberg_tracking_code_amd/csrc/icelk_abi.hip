@@ -277,11 +277,13 @@ static int check_slot(Ctx* c, int slot, bool need_image)
     return ICELK_OK;
 }
 
+static int wait_event(Ctx* c, hipStream_t s, hipEvent_t e);
+
 static int wait_slot(Ctx* c, int slot)
 {
     Slot& s = c->slots[slot];
     if (s.pending) {
-        HIPCHK(c, hipStreamWaitEvent(c->stream, s.ready, 0));
+        if (int rcw = wait_event(c, c->stream, s.ready)) return rcw;
         s.pending = false;
     }
     return ICELK_OK;
@@ -319,7 +321,7 @@ static int begin_frame(Ctx* c, int slot, int w, int h)
     Slot& s = c->slots[slot];
     // a detector launch on another stream may still read the frame this slot holds (compute-stream ingest paths
     // write level 0 right after this call; the copy-stream path waits for the same event itself)
-    HIPCHK(c, hipStreamWaitEvent(c->stream, s.det_used, 0));
+    if (int rcw = wait_event(c, c->stream, s.det_used)) return rcw;
     s.w = w;
     s.h = h;
     layout_levels(s, w, h);
@@ -474,6 +476,8 @@ static void destroy_ctx(Ctx* c)
     if (c->seg_ready) hipEventDestroy(c->seg_ready);
     for (auto& b : c->sb)
         if (b.used_own) hipEventDestroy(b.used_own);
+    for (auto& e : c->launch_ev)
+        if (e) hipEventDestroy(e);
     for (auto& e : c->eo)
         if (e.done) hipEventDestroy(e.done);
     if (c->h_counts) hipHostFree(c->h_counts);
@@ -553,7 +557,7 @@ static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
         return ICELK_OK;   // already there
     const hipStream_t es = c->eig_stream;
     // level 0 only: `ready` would also wait for a pyramid built ahead, which the detector never reads
-    HIPCHK(c, hipStreamWaitEvent(es, s.frame_ev, 0));
+    if (int rcw = wait_event(c, es, s.frame_ev)) return rcw;
     HIPCHK(c, hipMemsetAsync(e.max_key, 0, sizeof(unsigned), es));
     DetectScratch T = c->D;
     T.raw = e.raw;
@@ -604,8 +608,8 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
     }
     // the frame must be in the slot (ingest on the compute or the copy stream), and the tail that sorted the buffer of
     // accepted keys this detection writes (two detections ago) must have read it; nothing else orders the streams
-    HIPCHK(c, hipStreamWaitEvent(ds, s.frame_ev, 0));   // level 0 only (see detect_prepare)
-    HIPCHK(c, hipStreamWaitEvent(ds, c->acc_read[c->acc_idx], 0));
+    if (int rcw = wait_event(c, ds, s.frame_ev)) return rcw;   // level 0 only (see detect_prepare)
+    if (int rcw = wait_event(c, ds, c->acc_read[c->acc_idx])) return rcw;
     const bool generic = getenv("ICELK_GENERIC_CORNERS") != nullptr;
     // counters are normally left zeroed by the previous detection (the reset runs after its last kernel,
     // off the critical path); reset here only the first time or when the cell grid grew
@@ -617,7 +621,7 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
     if (prepared) {
         if (need_reset) launch_detect_reset(ds, D, (int)ncell, true);   // before the swap: the prepared maximum stays
         activate_eig_out(c, c->eo_active ^ 1);
-        HIPCHK(c, hipStreamWaitEvent(ds, spare.done, 0));
+        if (int rcw = wait_event(c, ds, spare.done)) return rcw;
     } else {
         ProfScope p(c, K_EIG, ds);
         if (need_reset) launch_detect_reset(ds, D, (int)ncell, true);
@@ -704,7 +708,7 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
         c->last_candidates = total;
         c->last_accepted = total;
         if (total == 0) return ICELK_OK;
-        HIPCHK(c, hipStreamWaitEvent(ds, c->det_done, 0));   // sort scratch: an earlier tail may still use it
+        if (int rcw = wait_event(c, ds, c->det_done)) return rcw;   // sort scratch: an earlier tail may still use it
         sort_keys_desc(ds, D, D.cand, D.cell_cand, total);
         sorted = D.cell_cand;
     }
@@ -713,7 +717,7 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
     int n = total;
     if (max_corners > 0 && n > max_corners) n = max_corners;
     if (n > cap || n > c->max_pts) FAIL(c, ICELK_ECAP, "more corners than the output capacity (raise max_pts)");
-    HIPCHK(c, hipStreamWaitEvent(ts, c->corners_free, 0));   // the previous corner list has been consumed
+    if (int rcw = wait_event(c, ts, c->corners_free)) return rcw;   // the previous corner list has been consumed
     {
         ProfScope p(c, K_EMIT, ts);
         launch_emit_corners(ts, sorted, n, J.w, c->d_corners);
@@ -741,7 +745,7 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
 static int seg_wait(Ctx* c)
 {
     if (c->seg_ready_pending) {
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->seg_ready, 0));
+        if (int rcw = wait_event(c, c->stream, c->seg_ready)) return rcw;
         c->seg_ready_pending = false;
     }
     return ICELK_OK;
@@ -1032,7 +1036,20 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
             c->err = "hipEventCreate failed";
             return fail(ICELK_EHIP);
         }
+        s.used = s.used_own;
     }
+    for (auto& S : c->sb) {
+        if (hipEventCreateWithFlags(&S.used_own, hipEventDisableTiming) != hipSuccess) {
+            c->err = "hipEventCreate failed";
+            return fail(ICELK_EHIP);
+        }
+        S.used = S.used_own;
+    }
+    for (auto& e : c->launch_ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            c->err = "hipEventCreate failed";
+            return fail(ICELK_EHIP);
+        }
     const size_t npx = (size_t)max_w * max_h;
     c->bgr_pitch = align_up(3 * max_w, kPitchAlign);
     c->mask_pitch = align_up(max_w, kPitchAlign);
@@ -1171,8 +1188,8 @@ int icelk_upload_gray_async(icelk_t* h, int slot, const uint8_t* pinned_host, in
     if (rc) return rc;
     Slot& s = c->slots[slot];
     // the copy must not overtake the launches that still read this slot (Slot::used / det_used)
-    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, s.used, 0));
-    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, s.det_used, 0));
+    if (int rcw = wait_event(c, c->copy_stream, s.used)) return rcw;
+    if (int rcw = wait_event(c, c->copy_stream, s.det_used)) return rcw;
     HIPCHK(c, hipMemcpy2DAsync(s.lv[0].ptr, s.lv[0].pitch, pinned_host, stride, w, h_, hipMemcpyHostToDevice,
                                c->copy_stream));
     HIPCHK(c, hipEventRecord(s.ready, c->copy_stream));
@@ -1347,9 +1364,9 @@ int icelk_build_pyramid_ahead(icelk_t* h, int slot, int win_w, int win_h, int ma
     const hipStream_t cs = c->copy_stream;
     // level 0 must be there (it may have been written on the compute stream), and launches that still read the
     // slot's previous pyramid must be through
-    HIPCHK(c, hipStreamWaitEvent(cs, s.frame_ev, 0));
-    if (s.pending) HIPCHK(c, hipStreamWaitEvent(cs, s.ready, 0));
-    HIPCHK(c, hipStreamWaitEvent(cs, s.used, 0));
+    if (int rcw = wait_event(c, cs, s.frame_ev)) return rcw;
+    if (s.pending) if (int rcw = wait_event(c, cs, s.ready)) return rcw;
+    if (int rcw = wait_event(c, cs, s.used)) return rcw;
     rc = build_levels(c, s, top, cs);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(s.ready, cs));
@@ -1647,7 +1664,7 @@ static int seg_stage(Ctx* c, int max_corners, int* out_n)
     // that still touch that set (the segment before the closing one) must be through
     Ctx::SegBuf& nb = c->sb[(c->sb_cur + 1) % kSegSets];
     const hipStream_t ds = c->corners_stream;   // right behind the corner list
-    HIPCHK(c, hipStreamWaitEvent(ds, nb.used, 0));
+    if (int rcw = wait_event(c, ds, nb.used)) return rcw;
     launch_seg_init(ds, c->d_corners, n, nb.live, nb.alive, nb.tracks, kMaxVert);
     if (c->use_order) launch_seg_order(ds, c->d_corners, n, c->job.w, c->job.h, c->border_px, nb.order, nb.order_border);
     rc = check_launch(c, "seg_init");
