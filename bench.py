@@ -236,13 +236,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
                     help="default: c2 on one GPU, c4 (sharded sequence + RCCL gather) on several")
-    ap.add_argument("--ring", type=int, default=24, help="distinct frames resident in HBM (c2 / c5 / ref)")
+    ap.add_argument("--ring", type=int, default=64, help="distinct frames resident in HBM (c2 / c5 / ref)")
     ap.add_argument("--motion", default="shear", choices=("shear", "translate"),
                     help="frame-to-frame motion of the synthetic sequence: sub-pixel translation plus a slowly varying "
                          "affine deformation of up to 0.5 %% (default), or translation only (the easiest case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="leave out the per-kernel HIP events (and with them the roofline object): shows what they cost")
+    ap.add_argument("--time-all-kernels", action="store_true",
+                    help="HIP-event timing of every kernel inside the timed region (default: the tracker launches only)")
     ap.add_argument("--no-pair-launch", action="store_true",
                     help="A/B: the last pair of a segment is launched on its own instead of with the first pair of the next")
     ap.add_argument("--no-lookahead", action="store_true",
@@ -354,7 +356,9 @@ def main():
     if linear:
         tracked0 = ctx.seg_live()[1] if warm.active else 0
     ctx.prof_reset()
-    ctx.prof_enable(not args.no_kernel_timing)
+    # the tracker launches are timed (HIP events on their stream); timing every kernel of the pipeline costs two event
+    # records per kernel on the detector's streams and 7 % of the throughput: --time-all-kernels
+    ctx.prof_enable(0 if args.no_kernel_timing else (1 if args.time_all_kernels else 2))
     barrier()
     t0 = time.perf_counter()
     run_resident(tracker, timed_order, t_first, pushes)
@@ -547,12 +551,13 @@ def main():
                                "note": "LK is VALU-issue-bound (SURVEY.md 8d); HBM fraction reported for completeness, the "
                                        "issue fraction is in valu_issue"}
         pd = prof.get("pyrdown")
-        if pd:
+        if pd or alone.get("pyrdown"):
             alg = pyramid_algorithmic_bytes(w, h, top)
-            per_frame_us = pd["total_ms"] * 1e3 / K
-            kern["pyramid"] = {"bound": "hbm", "algorithmic_bytes_per_frame": alg, "us_per_frame": per_frame_us,
-                               "achieved_GBps": alg / (per_frame_us * 1e-6) / 1e9,
-                               "frac": alg / (per_frame_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            kern["pyramid"] = {"bound": "hbm", "algorithmic_bytes_per_frame": alg}
+            if pd:
+                per_frame_us = pd["total_ms"] * 1e3 / K
+                kern["pyramid"].update(us_per_frame=per_frame_us, achieved_GBps=alg / (per_frame_us * 1e-6) / 1e9,
+                                       frac=alg / (per_frame_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
             if alone.get("pyrdown"):
                 a_us = alone["pyrdown"]["total_ms"] * 1e3 / 5.0
                 kern["pyramid"].update(alone_us_per_frame=a_us, alone_GBps=alg / (a_us * 1e-6) / 1e9,
@@ -563,12 +568,13 @@ def main():
             kern["bgr2gray"] = {"bound": "hbm", "algorithmic_bytes_per_frame": alg, "alone_us": a_us,
                                 "alone_GBps": alg / (a_us * 1e-6) / 1e9, "alone_frac": alg / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         eg = prof.get("corner_candidates")
-        if eg:
+        if eg or alone.get("corner_candidates"):
             alg = 1.0 * w * h   # 1 B/px in; the eigenvalue map is never materialised (k_corners.hip)
-            kern["corner_candidates"] = {"bound": "hbm", "algorithmic_bytes_per_launch": alg, "avg_launch_us": eg["avg_us"],
-                                         "achieved_GBps": alg / (eg["avg_us"] * 1e-6) / 1e9,
-                                         "frac": alg / (eg["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            kern["corner_candidates"] = {"bound": "hbm", "algorithmic_bytes_per_launch": alg,
                                          "note": "f64 box sums: issue-bound, not HBM-bound (DESIGN.md 4.2)"}
+            if eg:
+                kern["corner_candidates"].update(avg_launch_us=eg["avg_us"], achieved_GBps=alg / (eg["avg_us"] * 1e-6) / 1e9,
+                                                 frac=alg / (eg["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
             if alone.get("corner_candidates"):
                 a_us = alone["corner_candidates"]["avg_us"]
                 kern["corner_candidates"].update(alone_us=a_us, alone_GBps=alg / (a_us * 1e-6) / 1e9,

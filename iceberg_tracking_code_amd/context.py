@@ -326,7 +326,8 @@ class Context:
 
     # -- measurement ----------------------------------------------------------------------------
     def prof_enable(self, on=True):
-        self._ck(self._lib.icelk_prof_enable(self._h, 1 if on else 0))
+        """on: False / True (every kernel) / 2 (tracker launches only: the other streams carry no event records)."""
+        self._ck(self._lib.icelk_prof_enable(self._h, int(on)))
 
     def prof_reset(self):
         self._ck(self._lib.icelk_prof_reset(self._h))

@@ -33,21 +33,13 @@ struct Ctx {
     int device = 0;
     int max_w = 0, max_h = 0, n_slots = 0, max_pts = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
+    // pyramids built ahead of their step: not on the copy stream, where a 12 MB upload of a LATER frame would stand
+    // between a pyramid and the tracker launch that waits for it
+    hipStream_t pyr_stream = nullptr;
+    int side_pick[3] = {-1, -1, -1};   // which of the probed candidate streams became detection / candidates / pyramid
     // Detection (corner candidates, min-distance, sort) runs on its own stream: it only needs the frame,
     // not the tracker's results, so it overlaps the LK launch of the same frame (s1:323-326 vs s1:437).
     hipStream_t det_stream = nullptr;
-    // The tail of a detection -- sort of the accepted corners, the corner list, the new segment's initialisation -- runs
-    // on a stream of its own: the detection stream is a serial chain of ~10 short kernels per detection that takes most
-    // of a tracker launch to get through beside that launch, and with the tail (~10 more) behind it on the same stream
-    // the chain of the NEXT detection could not start before the tail was through.  The accepted keys the tail sorts
-    // are double buffered (acc_buf) so that the next min-distance stage may write while the tail still reads.
-    // ICELK_NO_TAIL_STREAM=1 keeps the tail on the detection stream (A/B).
-    hipStream_t tail_stream = nullptr;
-    hipStream_t corners_stream = nullptr;   // where d_corners was produced (tail_stream or det_stream)
-    unsigned long long* acc_buf[2] = {nullptr, nullptr};
-    int acc_idx = 0;                        // D.acc == acc_buf[acc_idx]
-    hipEvent_t acc_read[2] = {nullptr, nullptr};   // the tail that sorted acc_buf[i] has read it
-    bool use_tail_stream = true;
     hipEvent_t det_done = nullptr;      // corners of the latest detection are in d_corners
     hipEvent_t corners_free = nullptr;  // the compute stream has consumed d_corners
     std::vector<Slot> slots;
@@ -155,7 +147,8 @@ struct Ctx {
 
     // profiling
     bool prof = false;
-    std::vector<ProfEvt> evts;
+    bool prof_tracker_only = false;   // icelk_prof_enable(h, 2): every other kernel goes untimed (no event records on its stream)
+    std::vector<ProfEvt> evts, evt_pool;
     int prof_launches[K_COUNT_] = {0};
     double prof_ms[K_COUNT_] = {0};
 };
@@ -197,20 +190,27 @@ struct ProfScope {
     ProfEvt ev{};
     ProfScope(Ctx* c_, int id_, hipStream_t st_ = nullptr) : c(c_), id(id_), st(st_ ? st_ : c_->stream)
     {
-        if (c->prof) {
-            hipEventCreate(&ev.a);
-            hipEventCreate(&ev.b);
+        on = c->prof && (!c->prof_tracker_only || id == K_LK_FB || id == K_LK_FB_PAIR || id == K_LK);
+        if (on) {
+            if (!c->evt_pool.empty()) {
+                ev = c->evt_pool.back();
+                c->evt_pool.pop_back();
+            } else {
+                hipEventCreate(&ev.a);
+                hipEventCreate(&ev.b);
+            }
             ev.id = id;
             hipEventRecord(ev.a, st);
         }
     }
     ~ProfScope()
     {
-        if (c->prof) {
+        if (on) {
             hipEventRecord(ev.b, st);
             c->evts.push_back(ev);
         }
     }
+    bool on = false;
 };
 
 static void prof_drain(Ctx* c)
@@ -222,8 +222,7 @@ static void prof_drain(Ctx* c)
             c->prof_ms[e.id] += ms;
             c->prof_launches[e.id] += 1;
         }
-        hipEventDestroy(e.a);
-        hipEventDestroy(e.b);
+        c->evt_pool.push_back(e);   // reused by later scopes, destroyed with the handle
     }
     c->evts.clear();
 }
@@ -341,7 +340,7 @@ static int build_levels(Ctx* c, Slot& s, int top_level, hipStream_t st)
         {
             ProfScope p(c, K_PYRDOWN, st);
             if (per_level) launch_pyrdown(st, s.lv[l - 1], s.lv[l]);
-            else launch_pyramid_fused(st, s.lv, l - 1, n, c->pyr_ahead_one_wave && st == c->copy_stream);
+            else launch_pyramid_fused(st, s.lv, l - 1, n, c->pyr_ahead_one_wave && st == c->pyr_stream);
         }
         int rc = check_launch(c, "pyramid");
         if (rc) return rc;
@@ -415,8 +414,12 @@ static int dmalloc(Ctx* c, T** p, size_t count)
 
 // the detection chain is ~20 short kernels; a high-priority queue keeps each of them from waiting behind
 // the thousands of pending workgroups of the tracker launch it overlaps with
-static hipError_t create_priority_stream(hipStream_t* s)
+static hipError_t create_priority_stream(hipStream_t* s, const char* name = "")
 {
+    // A/B: ICELK_NORMAL_PRIO=det,pyr,eig creates the named streams at normal priority (the detection stream at normal
+    // priority costs 20 % of C2's throughput; the other two make no difference)
+    const char* e0 = getenv("ICELK_NORMAL_PRIO");
+    if (e0 && *name && strstr(e0, name)) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     int least = 0, greatest = 0;
     hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (e != hipSuccess) return e;
@@ -437,12 +440,118 @@ static hipError_t create_compute_stream(hipStream_t* s)
     return hipExtStreamCreateWithCUMask(s, 8, mask);
 }
 
+// ---- which hardware queue a side stream lands on matters --------------------------------------------------------------
+// The runtime backs every HIP stream with a hardware queue, and the queues sit on a handful of dispatch pipes.  A pipe
+// works on one dispatch at a time: while the tracker launch -- ten thousand workgroups, most of them waiting for a wave
+// slot for most of the launch -- occupies its pipe, a kernel of ANOTHER queue on the same pipe is not even looked at
+// until the last tracker workgroup has gone out.  Which pipe a new stream gets depends on how many queues the process
+// has created before (the host framework's included), so it cannot be written down: it is measured.  Eight candidate
+// high-priority streams are created; a probe fills the device from stream A with workgroups that idle for ~25 us each
+// (~200 us in all) and times a one-wave kernel on stream B beside it -- it comes back after a few microseconds, or
+// together with the filler.  The detection stream must not be held up by the compute stream; the candidates stream
+// (one long kernel per detection) must not hold up the detection stream; the pyramid stream must be held up by neither
+// the compute nor the candidates stream.  Measured on C2: 5 050 pairs/s with the three on pipes of their own, 4 000
+// with the candidates stream behind the tracker's pipe.  ICELK_NO_STREAM_PROBE=1: creation order, no probe.
+__global__ void k_probe_idle(unsigned ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    for (int guard = 0; guard < 200000; guard++) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+__global__ void k_probe_tick(unsigned* out)
+{
+    if (out) *out = 1u;
+}
+
+// fraction of the filler's duration (on `busy`) after which a one-wave kernel on `side` completed: ~0.1 when the two
+// queues are served independently, ~1 when `side` waits for the filler's dispatch
+static double probe_pair(hipStream_t busy, hipStream_t side, hipEvent_t e_busy, hipEvent_t e_side)
+{
+    using clk = std::chrono::steady_clock;
+    hipStreamSynchronize(busy);
+    hipStreamSynchronize(side);
+    const auto t0 = clk::now();
+    hipLaunchKernelGGL(k_probe_idle, dim3(65536), dim3(64), 0, busy, 2500u);
+    hipEventRecord(e_busy, busy);
+    hipLaunchKernelGGL(k_probe_tick, dim3(1), dim3(64), 0, side, (unsigned*)nullptr);
+    hipEventRecord(e_side, side);
+    hipEventSynchronize(e_side);
+    const auto t1 = clk::now();
+    hipEventSynchronize(e_busy);
+    const auto t2 = clk::now();
+    const double whole = std::chrono::duration<double>(t2 - t0).count();
+    const double frac = whole > 0 ? std::chrono::duration<double>(t1 - t0).count() / whole : 1.0;
+    if (getenv("ICELK_STREAM_PROBE_LOG"))
+        fprintf(stderr, "icelk probe: busy %p side %p: side done after %.2f of %.0f us\n", (void*)busy, (void*)side, frac, 1e6 * whole);
+    return frac;
+}
+
+static hipError_t create_side_streams(Ctx* c)
+{
+    if (getenv("ICELK_NO_STREAM_PROBE")) {
+        hipError_t r = create_priority_stream(&c->det_stream, "det");
+        if (r == hipSuccess) r = create_priority_stream(&c->pyr_stream, "pyr");
+        if (r == hipSuccess) r = create_priority_stream(&c->eig_stream, "eig");
+        return r;
+    }
+    constexpr int NC = 8;
+    hipStream_t cand[NC] = {nullptr};
+    hipEvent_t ea = nullptr, eb = nullptr;
+    hipError_t r = hipEventCreateWithFlags(&ea, hipEventDisableTiming);
+    if (r == hipSuccess) r = hipEventCreateWithFlags(&eb, hipEventDisableTiming);
+    for (int i = 0; i < NC && r == hipSuccess; i++) r = create_priority_stream(&cand[i], "side");
+    if (r == hipSuccess) {
+        probe_pair(c->own_stream, cand[0], ea, eb);   // code object load, clocks
+        // every candidate beside the compute stream, twice; "held up" = clearly later than the quickest one
+        double beside[NC], quickest = 1.0;
+        for (int i = 0; i < NC; i++) {
+            beside[i] = std::min(probe_pair(c->own_stream, cand[i], ea, eb), probe_pair(c->own_stream, cand[i], ea, eb));
+            quickest = std::min(quickest, beside[i]);
+        }
+        const double limit = std::max(1.6 * quickest, quickest + 0.12);
+        bool used[NC] = {false};
+        auto pick = [&](auto ok) {
+            for (int i = 0; i < NC; i++)
+                if (!used[i] && beside[i] <= limit && ok(cand[i])) { used[i] = true; return i; }
+            for (int i = 0; i < NC; i++)        // nothing passes (fewer pipes than assumed): the least held up of the rest
+                if (!used[i]) { used[i] = true; return i; }
+            return 0;
+        };
+        const int d = pick([&](hipStream_t) { return true; });
+        c->det_stream = cand[d];
+        const int e = pick([&](hipStream_t s) { return probe_pair(s, c->det_stream, ea, eb) <= limit; });
+        c->eig_stream = cand[e];
+        const int q = pick([&](hipStream_t s) { return probe_pair(c->eig_stream, s, ea, eb) <= limit; });
+        c->pyr_stream = cand[q];
+        c->side_pick[0] = d;
+        c->side_pick[1] = e;
+        c->side_pick[2] = q;
+        if (getenv("ICELK_STREAM_PROBE_LOG"))
+            fprintf(stderr, "icelk probe: detection = candidate %d, candidates stream = %d, pyramid = %d (limit %.2f)\n", d, e, q, limit);
+        for (int i = 0; i < NC; i++)
+            if (!used[i]) hipStreamDestroy(cand[i]);
+    } else {
+        for (auto s : cand)
+            if (s) hipStreamDestroy(s);
+    }
+    if (ea) hipEventDestroy(ea);
+    if (eb) hipEventDestroy(eb);
+    return r;
+}
+
 static void destroy_ctx(Ctx* c)
 {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     prof_drain(c);
+    for (auto& e : c->evt_pool) {
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
     if (c->d_stamps) {
         std::vector<unsigned long long> hs(3 * c->stamps_cap);
         if (hipMemcpy(hs.data(), c->d_stamps, hs.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -466,12 +575,6 @@ static void destroy_ctx(Ctx* c)
     if (c->det_done) hipEventDestroy(c->det_done);
     if (c->corners_free) hipEventDestroy(c->corners_free);
     if (c->det_stream) hipStreamDestroy(c->det_stream);
-    if (c->tail_stream) {
-        hipStreamSynchronize(c->tail_stream);
-        hipStreamDestroy(c->tail_stream);
-    }
-    for (auto& e : c->acc_read)
-        if (e) hipEventDestroy(e);
     if (c->eig_stream) hipStreamDestroy(c->eig_stream);
     if (c->seg_ready) hipEventDestroy(c->seg_ready);
     for (auto& b : c->sb)
@@ -485,7 +588,7 @@ static void destroy_ctx(Ctx* c)
     void* ptrs[] = {c->d_bgr, c->d_mask, c->d_p0, c->d_p1, c->d_p0r, c->d_err_f, c->d_err_b, c->d_dist, c->d_corners,
                     c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.cand, c->D.cand_count,
                     c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.chunk_tot, c->D.cell_cand, c->D.state, c->D.undecided,
-                    c->acc_buf[0], c->acc_buf[1], c->D.acc_sorted, c->D.acc_count, c->eo[0].raw, c->eo[1].raw, c->eo[0].blk_count, c->eo[1].blk_count,
+                    c->D.acc, c->D.acc_sorted, c->D.acc_count, c->eo[0].raw, c->eo[1].raw, c->eo[0].blk_count, c->eo[1].blk_count,
                     c->eo[0].max_key, c->eo[1].max_key, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->d_tracked,
                     c->d_out_tracks, c->d_out_quality, c->d_proj, c->d_keep};
     for (void* p : ptrs)
@@ -497,6 +600,10 @@ static void destroy_ctx(Ctx* c)
     }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    if (c->pyr_stream) {
+        hipStreamSynchronize(c->pyr_stream);
+        hipStreamDestroy(c->pyr_stream);
+    }
     delete c;
 }
 
@@ -606,10 +713,10 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
         ncell = (size_t)((w + cell - 1) / cell) * ((h + cell - 1) / cell);
         if (ncell + 1 > c->ncell_cap) FAIL(c, ICELK_ECAP, "cell grid larger than allocated");
     }
-    // the frame must be in the slot (ingest on the compute or the copy stream), and the tail that sorted the buffer of
-    // accepted keys this detection writes (two detections ago) must have read it; nothing else orders the streams
+    // the frame must be in the slot (ingest on the compute or the copy stream) and the previous corner list
+    // must have been consumed before this detection overwrites it; nothing else orders the two streams
     if (int rcw = wait_event(c, ds, s.frame_ev)) return rcw;   // level 0 only (see detect_prepare)
-    if (int rcw = wait_event(c, ds, c->acc_read[c->acc_idx])) return rcw;
+    if (int rcw = wait_event(c, ds, c->corners_free)) return rcw;
     const bool generic = getenv("ICELK_GENERIC_CORNERS") != nullptr;
     // counters are normally left zeroed by the previous detection (the reset runs after its last kernel,
     // off the critical path); reset here only the first time or when the cell grid grew
@@ -663,10 +770,6 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
     J.active = false;
     *n_out = 0;
     const hipStream_t ds = c->det_stream;
-    // everything after the host round trip: on the tail stream (the detection stream has been waited for: whatever it
-    // produced is there), except when the keys to sort are not double buffered (minDistance < 1)
-    const hipStream_t ts = (J.min_distance >= 1 && c->use_tail_stream) ? c->tail_stream : ds;
-    c->corners_stream = ts;
     DetectScratch& D = c->D;
     int rc = fetch_counts(c);   // the one host round trip of a detection: {candidates, accepted, undecided}
     if (rc) return rc;
@@ -695,20 +798,13 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
         c->last_candidates = c->h_counts[0];
         c->last_accepted = total;
         if (total == 0) return ICELK_OK;
-        sort_keys_desc(ts, D, D.acc, D.acc_sorted, total);
+        sort_keys_desc(ds, D, D.acc, D.acc_sorted, total);
         sorted = D.acc_sorted;
-        if (ts != ds) {
-            // the next min-distance stage writes the other buffer
-            HIPCHK(c, hipEventRecord(c->acc_read[c->acc_idx], ts));
-            c->acc_idx ^= 1;
-            D.acc = c->acc_buf[c->acc_idx];
-        }
     } else {
         total = c->h_counts[0];
         c->last_candidates = total;
         c->last_accepted = total;
         if (total == 0) return ICELK_OK;
-        if (int rcw = wait_event(c, ds, c->det_done)) return rcw;   // sort scratch: an earlier tail may still use it
         sort_keys_desc(ds, D, D.cand, D.cell_cand, total);
         sorted = D.cell_cand;
     }
@@ -717,14 +813,13 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
     int n = total;
     if (max_corners > 0 && n > max_corners) n = max_corners;
     if (n > cap || n > c->max_pts) FAIL(c, ICELK_ECAP, "more corners than the output capacity (raise max_pts)");
-    if (int rcw = wait_event(c, ts, c->corners_free)) return rcw;   // the previous corner list has been consumed
     {
-        ProfScope p(c, K_EMIT, ts);
-        launch_emit_corners(ts, sorted, n, J.w, c->d_corners);
+        ProfScope p(c, K_EMIT, ds);
+        launch_emit_corners(ds, sorted, n, J.w, c->d_corners);
     }
     rc = check_launch(c, "emit");
     if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->det_done, ts));
+    HIPCHK(c, hipEventRecord(c->det_done, ds));
     launch_detect_reset(ds, D, (int)J.ncell, true);   // for the next detection
     c->reset_ncell = J.ncell;
     c->counters_clean = true;
@@ -1005,14 +1100,9 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         return code;
     };
     if (create_compute_stream(&c->own_stream) != hipSuccess ||
-        // uploads and pyramids built ahead: short kernels the NEXT tracker launch waits for, issued beside the current one
-        (getenv("ICELK_COPY_STREAM_NORMAL") ? hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)
-                                            : create_priority_stream(&c->copy_stream)) != hipSuccess ||
-        create_priority_stream(&c->det_stream) != hipSuccess ||
-        create_priority_stream(&c->tail_stream) != hipSuccess ||
-        hipEventCreateWithFlags(&c->acc_read[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->acc_read[1], hipEventDisableTiming) != hipSuccess ||
-        create_priority_stream(&c->eig_stream) != hipSuccess ||
+        // uploads are DMA copies: normal priority; pyramid, detection and candidates are the high-priority streams
+        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        create_side_streams(c) != hipSuccess ||
         hipEventCreateWithFlags(&c->seg_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->eo[0].done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->eo[1].done, hipEventDisableTiming) != hipSuccess ||
@@ -1068,7 +1158,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &D.cell_count, c->ncell_cap)) || (rc = dmalloc(c, &D.cell_start, c->ncell_cap)) ||
         (rc = dmalloc(c, &D.cell_fill, c->ncell_cap)) || (rc = dmalloc(c, &D.chunk_tot, (c->ncell_cap / 2048 + 2) * 32)) || (rc = dmalloc(c, &D.cell_cand, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.state, (size_t)D.cand_cap)) || (rc = dmalloc(c, &D.undecided, 64)) ||
-        (rc = dmalloc(c, &c->acc_buf[0], (size_t)D.cand_cap)) || (rc = dmalloc(c, &c->acc_buf[1], (size_t)D.cand_cap)) ||
+        (rc = dmalloc(c, &D.acc, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.acc_sorted, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, &c->eo[0].blk_count, candidate_blocks(max_w, max_h) * 4)) ||
         (rc = dmalloc(c, &c->eo[1].blk_count, candidate_blocks(max_w, max_h) * 4)) ||
@@ -1076,7 +1166,6 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &c->d_tracked, 64)) || (rc = dmalloc(c, &c->d_out_tracks, np * kMaxVert * 2)) ||
         (rc = dmalloc(c, &c->d_out_quality, np * (kMaxVert - 1))))
         return fail(rc);
-    D.acc = c->acc_buf[0];
     for (auto& S : c->sb)
         if ((rc = dmalloc(c, &S.live, 2 * np)) || (rc = dmalloc(c, &S.alive, np)) || (rc = dmalloc(c, &S.order, np)) ||
             (rc = dmalloc(c, &S.order_border, 1)) || (rc = dmalloc(c, &S.tracks, np * kMaxVert * 2)) ||
@@ -1085,7 +1174,6 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
     c->use_order = getenv("ICELK_NO_ORDER") == nullptr;
     c->border_first = getenv("ICELK_NO_BORDER_FIRST") == nullptr;
     c->pyr_per_level = getenv("ICELK_PYR_PER_LEVEL") != nullptr;
-    c->use_tail_stream = getenv("ICELK_NO_TAIL_STREAM") == nullptr;
     c->pyr_ahead_one_wave = getenv("ICELK_PYR_AHEAD_WIDE") == nullptr;
     if (!c->border_first) c->border_px = 0;
     if ((rc = dmalloc(c, &c->d_iters, (size_t)max_pts))) return fail(rc);
@@ -1134,9 +1222,9 @@ int icelk_sync(icelk_t* h)
     // every stream of the handle: uploads / pyramids built ahead, candidate kernels of a prepared detection
     // (icelk_seg_detect_prepare), the min-distance / sort / emit stage, tracker launches
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->pyr_stream));
     HIPCHK(c, hipStreamSynchronize(c->eig_stream));
     HIPCHK(c, hipStreamSynchronize(c->det_stream));
-    HIPCHK(c, hipStreamSynchronize(c->tail_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ICELK_OK;
 }
@@ -1189,6 +1277,7 @@ int icelk_upload_gray_async(icelk_t* h, int slot, const uint8_t* pinned_host, in
     Slot& s = c->slots[slot];
     // the copy must not overtake the launches that still read this slot (Slot::used / det_used)
     if (int rcw = wait_event(c, c->copy_stream, s.used)) return rcw;
+    if (s.pending) if (int rcw = wait_event(c, c->copy_stream, s.ready)) return rcw;   // a pyramid being built ahead from the old frame
     if (int rcw = wait_event(c, c->copy_stream, s.det_used)) return rcw;
     HIPCHK(c, hipMemcpy2DAsync(s.lv[0].ptr, s.lv[0].pitch, pinned_host, stride, w, h_, hipMemcpyHostToDevice,
                                c->copy_stream));
@@ -1361,7 +1450,7 @@ int icelk_build_pyramid_ahead(icelk_t* h, int slot, int win_w, int win_h, int ma
     Slot& s = c->slots[slot];
     const int top = pyramid_top_level(s.w, s.h, win_w, win_h, max_level);
     if (s.levels_built >= top + 1) return ICELK_OK;
-    const hipStream_t cs = c->copy_stream;
+    const hipStream_t cs = c->pyr_stream;
     // level 0 must be there (it may have been written on the compute stream), and launches that still read the
     // slot's previous pyramid must be through
     if (int rcw = wait_event(c, cs, s.frame_ev)) return rcw;
@@ -1587,7 +1676,6 @@ int icelk_min_eig_map(icelk_t* h, int slot, int block_size, float* host_out, int
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));       // the frame is in place
     HIPCHK(c, hipStreamSynchronize(c->det_stream));   // the detector scratch is free
-    HIPCHK(c, hipStreamSynchronize(c->tail_stream));
     {
         ProfScope p(c, K_EIG);
         launch_detect_reset(c->stream, c->D, 0, true);
@@ -1617,8 +1705,8 @@ int icelk_good_features(icelk_t* h, int slot, int use_mask, int max_corners, dou
     int rc = detect_core(c, slot, use_mask, max_corners, quality_level, min_distance, block_size, cap, &n);
     if (rc) return rc;
     if (n > 0) {
-        HIPCHK(c, hipMemcpyAsync(out_xy, c->d_corners, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->corners_stream));
-        HIPCHK(c, hipStreamSynchronize(c->corners_stream));
+        HIPCHK(c, hipMemcpyAsync(out_xy, c->d_corners, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->det_stream));
+        HIPCHK(c, hipStreamSynchronize(c->det_stream));
     }
     *out_n = n;
     return ICELK_OK;
@@ -1663,7 +1751,7 @@ static int seg_stage(Ctx* c, int max_corners, int* out_n)
     // the new segment goes into the other set, on the detection stream right behind the corner list; launches
     // that still touch that set (the segment before the closing one) must be through
     Ctx::SegBuf& nb = c->sb[(c->sb_cur + 1) % kSegSets];
-    const hipStream_t ds = c->corners_stream;   // right behind the corner list
+    const hipStream_t ds = c->det_stream;
     if (int rcw = wait_event(c, ds, nb.used)) return rcw;
     launch_seg_init(ds, c->d_corners, n, nb.live, nb.alive, nb.tracks, kMaxVert);
     if (c->use_order) launch_seg_order(ds, c->d_corners, n, c->job.w, c->job.h, c->border_px, nb.order, nb.order_border);
@@ -2073,6 +2161,7 @@ int icelk_prof_enable(icelk_t* h, int on)
     Ctx* c = C(h);
     if (!on) prof_drain(c);
     c->prof = on != 0;
+    c->prof_tracker_only = on == 2;
     return ICELK_OK;
 }
 

@@ -11,12 +11,13 @@
  *   - the caller owns every host buffer; the library owns all device memory (frames, pyramids, points).
  *   - a handle is bound to one GPU and is not thread-safe; use one handle per thread/process.
  *     Multi-GPU = one process per GPU, one handle each (DESIGN.md "Multi-GPU").
- *   - a handle owns FOUR HIP streams: compute (tracker launches, segment bookkeeping; replaceable by the
- *     caller's stream, icelk_set_stream), copy (icelk_upload_gray_async, icelk_build_pyramid_ahead), detection
- *     (min-distance stage, sort, emit) and candidates (the corner kernel of icelk_seg_detect_prepare).  They are
- *     ordered against each other by events inside the library; a call whose outputs are host buffers has
- *     finished with them when it returns.  icelk_sync waits for ALL four: after it nothing of the handle
- *     reads or writes any slot, mask or point buffer.
+ *   - a handle owns FIVE HIP streams: compute (tracker launches, segment bookkeeping; replaceable by the
+ *     caller's stream, icelk_set_stream), copy (icelk_upload_gray_async), pyramid (icelk_build_pyramid_ahead),
+ *     detection (min-distance stage, sort, corner list, the new segment's tables)
+ *     and candidates (the corner kernel of icelk_seg_detect_prepare).  They are ordered against each other by
+ *     events inside the library; a call whose outputs are host buffers has finished with them when it returns.
+ *     icelk_sync waits for ALL of them (and launches a pair held back by icelk_seg_track_defer first): after it
+ *     nothing of the handle reads or writes any slot, mask or point buffer.
  *   - "slot" = a device-resident frame with its Gaussian pyramid.  Slots let the caller keep the
  *     previous frame (prev_gray = frame_gray, s1:450) and its pyramid on the GPU instead of
  *     rebuilding both pyramids in every cv2.calcOpticalFlowPyrLK call as OpenCV does.
@@ -267,7 +268,9 @@ int icelk_grid_bin(icelk_t* h, const double* x, const double* y, const double* u
                    double* mean_v, double* speed);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
-/* Per-kernel HIP-event timing on the handle's stream (bench.py's roofline leg). */
+/* Per-kernel HIP-event timing on the handle's streams (bench.py's roofline leg).  on = 1: every kernel; on = 2: the
+ * tracker launches only (each timed kernel costs two event records on its stream, which the chains of short detector
+ * kernels feel); on = 0: off, durations collected so far are added up. */
 int icelk_prof_enable(icelk_t* h, int on);
 int icelk_prof_reset(icelk_t* h);
 /* LK iterations every feature of the latest tracker call ran while profiling was enabled: forward pass in the low 16
