@@ -245,6 +245,8 @@ def main():
                     help="leave out the per-kernel HIP events (and with them the roofline object): shows what they cost")
     ap.add_argument("--time-all-kernels", action="store_true",
                     help="HIP-event timing of every kernel inside the timed region (default: the tracker launches only)")
+    ap.add_argument("--pcie-depth", type=int, default=4, help="c3: uploads in flight ahead of the tracker in the PCIe-inclusive run")
+    ap.add_argument("--pcie-spare-slots", type=int, default=6, help="c3: slots beyond the uploads in flight (previous + current + spares)")
     ap.add_argument("--no-pair-launch", action="store_true",
                     help="A/B: the last pair of a segment is launched on its own instead of with the first pair of the next")
     ap.add_argument("--no-lookahead", action="store_true",
@@ -430,9 +432,12 @@ def main():
             pinned.append(ptr)
         ctx.close()   # one handle (four streams) on the device at a time
         ctx = None
-        hctx = Context(w, h, n_slots=6, max_pts=max_pts, device=local_rank)
-        ht = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=hctx, lookahead=not args.no_lookahead)
-        depth = 3   # uploads in flight ahead of the frame being tracked (6 slots: previous, current, three coming, one spare)
+        depth = args.pcie_depth   # uploads in flight ahead of the frame being tracked
+        n_up_slots = depth + args.pcie_spare_slots   # previous, current, `depth` coming, and spares: the slot an upload
+        # overwrites was last read several launches ago, so the copy never waits for the launch that is running
+        hctx = Context(w, h, n_slots=n_up_slots, max_pts=max_pts, device=local_rank)
+        ht = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=hctx, lookahead=not args.no_lookahead,
+                            pair_launch=not args.no_pair_launch)
         hctx.sync()
         torch.cuda.synchronize()
         h0 = time.perf_counter()
@@ -449,7 +454,7 @@ def main():
         # same frames, same loop: the survivors must agree with the resident run
         pcie = dict(value=(len(pinned) - 1) / (h1 - h0), unit="frame-pairs/s", pairs=len(pinned) - 1,
                     tracked_features_per_sec=htracked / (h1 - h0), live_tracks_equal_resident_run=bool(ht.live()[0] == n_live),
-                    source="pinned host memory, hipMemcpyAsync, %d uploads in flight ahead of the tracker (6 slots)" % depth,
+                    source="pinned host memory, hipMemcpyAsync, %d uploads in flight ahead of the tracker (%d slots)" % (depth, n_up_slots),
                     bytes_per_frame=w * h, note="includes the first frame's upload and the first (blocking) detection")
         for ptr in pinned:
             hctx.host_free(ptr)

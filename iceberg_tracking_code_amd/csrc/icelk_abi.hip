@@ -33,6 +33,11 @@ struct Ctx {
     int device = 0;
     int max_w = 0, max_h = 0, n_slots = 0, max_pts = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
+    // Asynchronous uploads alternate between two streams: between two copies of ONE stream the runtime spends ~50 us
+    // (completion signal of the first, dependency of the second: 220 us copies came out 270 us apart), which a copy
+    // queued on the other stream fills
+    hipStream_t copy_stream2 = nullptr;
+    unsigned upload_seq = 0;
     // pyramids built ahead of their step: not on the copy stream, where a 12 MB upload of a LATER frame would stand
     // between a pyramid and the tracker launch that waits for it
     hipStream_t pyr_stream = nullptr;
@@ -600,6 +605,10 @@ static void destroy_ctx(Ctx* c)
     }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    if (c->copy_stream2) {
+        hipStreamSynchronize(c->copy_stream2);
+        hipStreamDestroy(c->copy_stream2);
+    }
     if (c->pyr_stream) {
         hipStreamSynchronize(c->pyr_stream);
         hipStreamDestroy(c->pyr_stream);
@@ -1102,6 +1111,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
     if (create_compute_stream(&c->own_stream) != hipSuccess ||
         // uploads are DMA copies: normal priority; pyramid, detection and candidates are the high-priority streams
         hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking) != hipSuccess ||
         create_side_streams(c) != hipSuccess ||
         hipEventCreateWithFlags(&c->seg_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->eo[0].done, hipEventDisableTiming) != hipSuccess ||
@@ -1222,6 +1232,7 @@ int icelk_sync(icelk_t* h)
     // every stream of the handle: uploads / pyramids built ahead, candidate kernels of a prepared detection
     // (icelk_seg_detect_prepare), the min-distance / sort / emit stage, tracker launches
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream2));
     HIPCHK(c, hipStreamSynchronize(c->pyr_stream));
     HIPCHK(c, hipStreamSynchronize(c->eig_stream));
     HIPCHK(c, hipStreamSynchronize(c->det_stream));
@@ -1275,14 +1286,14 @@ int icelk_upload_gray_async(icelk_t* h, int slot, const uint8_t* pinned_host, in
     int rc = begin_frame(c, slot, w, h_);
     if (rc) return rc;
     Slot& s = c->slots[slot];
+    const hipStream_t cs = (c->upload_seq++ & 1) ? c->copy_stream2 : c->copy_stream;
     // the copy must not overtake the launches that still read this slot (Slot::used / det_used)
-    if (int rcw = wait_event(c, c->copy_stream, s.used)) return rcw;
-    if (s.pending) if (int rcw = wait_event(c, c->copy_stream, s.ready)) return rcw;   // a pyramid being built ahead from the old frame
-    if (int rcw = wait_event(c, c->copy_stream, s.det_used)) return rcw;
-    HIPCHK(c, hipMemcpy2DAsync(s.lv[0].ptr, s.lv[0].pitch, pinned_host, stride, w, h_, hipMemcpyHostToDevice,
-                               c->copy_stream));
-    HIPCHK(c, hipEventRecord(s.ready, c->copy_stream));
-    HIPCHK(c, hipEventRecord(s.frame_ev, c->copy_stream));
+    if (int rcw = wait_event(c, cs, s.used)) return rcw;
+    if (s.pending) if (int rcw = wait_event(c, cs, s.ready)) return rcw;   // an upload or a pyramid built ahead still in flight
+    if (int rcw = wait_event(c, cs, s.det_used)) return rcw;
+    HIPCHK(c, hipMemcpy2DAsync(s.lv[0].ptr, s.lv[0].pitch, pinned_host, stride, w, h_, hipMemcpyHostToDevice, cs));
+    HIPCHK(c, hipEventRecord(s.ready, cs));
+    HIPCHK(c, hipEventRecord(s.frame_ev, cs));
     s.pending = true;
     s.levels_built = 1;
     return ICELK_OK;
