@@ -596,14 +596,18 @@ def main():
             # file; profiles/ holds the raw summaries it was made from)
             try:
                 pj = json.load(open(pmc_file))
-                out["roofline"]["traffic"] = pj.get("lk_fb_bytes_per_launch")
+                # the counters are per launch of the profiled run (joint launches: two frame pairs each); the launches of
+                # this run carry pairs_per_launch on average
+                scale = lkp["pairs_per_launch"] / float(pj.get("frame_pairs_per_launch", 1))
+                out["roofline"]["traffic"] = pj.get("lk_fb_bytes_per_launch") * scale if pj.get("lk_fb_bytes_per_launch") else None
                 out["roofline"]["traffic_source"] = pj.get("source")
                 vi = pj.get("lk_fb_valu_insts_per_launch")
                 if vi:
+                    vi *= scale
                     rate = vi / (out["roofline"]["avg_launch_us"] * 1e-6)
                     cyc = pj.get("valu_cycles_per_inst", {})
                     out["roofline"]["valu_issue"] = {
-                        "wave_instructions_per_launch": vi, "salu_instructions_per_launch": pj.get("lk_fb_salu_insts_per_launch"),
+                        "wave_instructions_per_launch": vi, "salu_instructions_per_launch": (pj.get("lk_fb_salu_insts_per_launch") or 0) * scale,
                         "achieved_per_s": rate,
                         "peak_per_s": {k: SIMDS * CLOCK_HZ / v for k, v in cyc.items()},
                         "frac": {k: rate / (SIMDS * CLOCK_HZ / v) for k, v in cyc.items()},

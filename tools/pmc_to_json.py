@@ -13,11 +13,26 @@ for line in open(summary):
         m = re.match(r"\s+(\S+)\s+n=(\d+)\s+mean=(\S+)", line)
         if m:
             blocks[cur][m.group(1)] = float(m.group(3))
-lk = next(v for k, v in blocks.items() if k.startswith("k_lk_fast") and "true" in k)
+# the tracker launches of the timed region: the largest grid (joint launches of two segment pairs in the default
+# pipeline; the single-pair launches of bench.py's "alone" section and of the first step have half the workgroups)
+counts = {}
+cur = None
+for line in open(summary):
+    if not line.startswith(" "):
+        cur = line.strip()
+    else:
+        m = re.match(r"\s+(\S+)\s+n=(\d+)", line)
+        if m:
+            counts[cur] = max(counts.get(cur, 0), int(m.group(2)))
+cands = [k for k in blocks if k.startswith("k_lk_fast") and "true" in k and "workgroups" in k]
+lk_name = max(cands, key=lambda k: int(re.search(r"\[(\d+) workgroups", k).group(1))) if cands else next(k for k in blocks if k.startswith("k_lk_fast") and "true" in k)
+lk = blocks[lk_name]
 kib = 1024.0
 out = {
     "source": source,
-    "kernel": next(k for k in blocks if k.startswith("k_lk_fast") and "true" in k),
+    "kernel": lk_name,
+    "launches_counted": counts.get(lk_name),
+    "frame_pairs_per_launch": 2 if len(cands) > 1 else 1,
     # FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE shows half the
     # bytes of WIDE (16 B/lane) coalesced reads; this kernel gathers single dwords, an access width the guide calls
     # uncalibrated -- the value is given as counted, and doubled as the upper bound
