@@ -419,30 +419,12 @@ static int dmalloc(Ctx* c, T** p, size_t count)
 
 // the detection chain is ~20 short kernels; a high-priority queue keeps each of them from waiting behind
 // the thousands of pending workgroups of the tracker launch it overlaps with
-static hipError_t create_priority_stream(hipStream_t* s, const char* name = "")
+static hipError_t create_priority_stream(hipStream_t* s)
 {
-    // A/B: ICELK_NORMAL_PRIO=det,pyr,eig creates the named streams at normal priority (the detection stream at normal
-    // priority costs 20 % of C2's throughput; the other two make no difference)
-    const char* e0 = getenv("ICELK_NORMAL_PRIO");
-    if (e0 && *name && strstr(e0, name)) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     int least = 0, greatest = 0;
     hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (e != hipSuccess) return e;
     return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
-}
-
-// The tracker's stream.  ICELK_TRACKER_CU_SKIP=<n> (experiment): the stream may not use the CUs of the first n mask bits,
-// which leaves them to the detector / copy streams whose short kernels otherwise queue for wave slots behind the
-// thousands of pending tracker workgroups.
-static hipError_t create_compute_stream(hipStream_t* s)
-{
-    const char* e = getenv("ICELK_TRACKER_CU_SKIP");
-    const int skip = e ? atoi(e) : 0;
-    if (skip <= 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-    uint32_t mask[8];
-    for (int i = 0; i < 8; i++) mask[i] = 0xffffffffu;
-    for (int i = 0; i < skip && i < 256; i++) mask[i >> 5] &= ~(1u << (i & 31));
-    return hipExtStreamCreateWithCUMask(s, 8, mask);
 }
 
 // ---- which hardware queue a side stream lands on matters --------------------------------------------------------------
@@ -497,9 +479,9 @@ static double probe_pair(hipStream_t busy, hipStream_t side, hipEvent_t e_busy, 
 static hipError_t create_side_streams(Ctx* c)
 {
     if (getenv("ICELK_NO_STREAM_PROBE")) {
-        hipError_t r = create_priority_stream(&c->det_stream, "det");
-        if (r == hipSuccess) r = create_priority_stream(&c->pyr_stream, "pyr");
-        if (r == hipSuccess) r = create_priority_stream(&c->eig_stream, "eig");
+        hipError_t r = create_priority_stream(&c->det_stream);
+        if (r == hipSuccess) r = create_priority_stream(&c->pyr_stream);
+        if (r == hipSuccess) r = create_priority_stream(&c->eig_stream);
         return r;
     }
     constexpr int NC = 8;
@@ -507,7 +489,7 @@ static hipError_t create_side_streams(Ctx* c)
     hipEvent_t ea = nullptr, eb = nullptr;
     hipError_t r = hipEventCreateWithFlags(&ea, hipEventDisableTiming);
     if (r == hipSuccess) r = hipEventCreateWithFlags(&eb, hipEventDisableTiming);
-    for (int i = 0; i < NC && r == hipSuccess; i++) r = create_priority_stream(&cand[i], "side");
+    for (int i = 0; i < NC && r == hipSuccess; i++) r = create_priority_stream(&cand[i]);
     if (r == hipSuccess) {
         probe_pair(c->own_stream, cand[0], ea, eb);   // code object load, clocks
         // every candidate beside the compute stream, twice; "held up" = clearly later than the quickest one
@@ -1108,7 +1090,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         destroy_ctx(c);
         return code;
     };
-    if (create_compute_stream(&c->own_stream) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         // uploads are DMA copies: normal priority; pyramid, detection and candidates are the high-priority streams
         hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking) != hipSuccess ||

@@ -180,7 +180,7 @@ class SegmentTracker:
         self.pair_launch = bool(pair_launch) and self.lookahead   # see `_step`: joint launch across a segment change
         self._pyr_ahead = set()   # slots whose pyramid was enqueued ahead of their step
         # how many steps ahead of a detection frame its min-distance stage / its corner candidates may start (`_step`)
-        self.begin_ahead, self.prepare_ahead = [int(v) for v in os.environ.get("ICELK_DET_AHEAD", "3,4").split(",")]
+        self.begin_ahead, self.prepare_ahead = 3, 4
         self._resident = False    # inside push_slot
         # callable(first_frame, closed) invoked once per finished segment, when all its pairs have been launched: e.g.
         # ctx.seg_archive(..., closed=closed).  closed=False: the segment is still the current one (the switch follows);
