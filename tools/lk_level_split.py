@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Tracker launch time against pyramid depth (maxLevel 0..3) at 1 and 2 forced iterations per level: per-workgroup
+constant (wave start, table look-ups, epilogue), per-level-pass fixed part, per-iteration part.  20 000 features."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from iceberg_tracking_code_amd import Context, synth  # noqa: E402
+
+w, h = 4000, 3000
+win = (21, 21)
+ctx = Context(w, h, n_slots=2, max_pts=1 << 16)
+sh = synth.shifts(3, seed=1234)
+ctx.synth_frame(0, w, h, int(sh[1, 0]), int(sh[1, 1]), 1234)
+ctx.synth_frame(1, w, h, int(sh[2, 0]), int(sh[2, 1]), 1234)
+pts = ctx.good_features(0, 20000, 0.007, 10, False, 10).reshape(-1, 2)
+n = len(pts)
+ctx.track_fb(0, 1, pts[:1000], win, 3)
+res = {}
+for ml in (0, 1, 2, 3):
+    for cnt in (1, 2):
+        ctx.track_fb(0, 1, pts, win, ml, criteria=(1, cnt, 0.0))
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        for _ in range(6):
+            ctx.track_fb(0, 1, pts, win, ml, criteria=(1, cnt, 0.0))
+        ctx.prof_enable(False)
+        res[(ml, cnt)] = ctx.prof_table()["lk_fb"]["avg_us"]
+        print("levels %d, iterations/level %d: %7.1f us" % (ml + 1, cnt, res[(ml, cnt)]))
+L = np.array([1, 2, 3, 4], float)
+t1 = np.array([res[(m, 1)] for m in range(4)])
+t2 = np.array([res[(m, 2)] for m in range(4)])
+b1, a1 = np.polyfit(L, t1, 1)
+b2, a2 = np.polyfit(L, t2, 1)
+print("n=%d, forward+backward: constant %.1f us; per level (2 passes) %.1f us with 1 iteration, +%.1f us for a 2nd iteration"
+      % (n, a1, b1, b2 - b1))
+ctx.close()
