@@ -118,7 +118,7 @@ struct Ctx {
     bool use_order = true;                 // ICELK_NO_ORDER=1 launches in detector order (A/B measurements)
     // features this close to the frame border count as slow (launched first): from the window and pyramid depth of the
     // latest tracker call; ICELK_NO_BORDER_FIRST=1 turns the class off
-    int border_px = (10 + 6 + 2) << 2;
+    int border_px = (10 + kLkTileMargin + 2) << 2;
     bool border_first = true;
     bool pyr_per_level = false;            // ICELK_PYR_PER_LEVEL=1: one pyrDown launch per level (A/B, second statement)
     // pyramids built ahead (copy stream, beside a tracker launch) use one-wave workgroups, which fit into the slot of a
@@ -954,7 +954,7 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
     if (rc) return rc;
     if (S.upper > 0) {
         // tiles (half window + search margin) of a feature this close to the edge reach over it at the upper levels
-        c->border_px = c->border_first ? ((std::max(win_w, win_h) / 2 + 6 + 2) << std::max(P.top_level - 1, 0)) : 0;
+        c->border_px = c->border_first ? ((std::max(win_w, win_h) / 2 + kLkTileMargin + 2) << std::max(P.top_level - 1, 0)) : 0;
         LKJob job = seg_job(c, c->sb_cur, s0, s1, P, true);
         const bool diag = c->d_stamps != nullptr;   // workgroup stamps describe ONE job: no pairing while they are on
         if (defer && !c->defer.pending && !diag) {

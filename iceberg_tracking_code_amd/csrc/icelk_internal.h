@@ -114,6 +114,9 @@ struct LKBuffers {
     // measurement (icelk_prof_enable): LK iterations each feature ran, forward pass in the low half, backward in the high
     uint32_t* iters;
 };
+// search-tile margin of the window-specialised tracker kernels (lk_fast_tiles.h); the host needs it to tell which features'
+// tiles reach over the frame border
+constexpr int kLkTileMargin = 1;
 // one tracker job: a frame pair and the features tracked across it
 struct LKJob {
     Pyramid I, J;

@@ -232,7 +232,10 @@ struct LKJobs {
 };
 
 template <int WW, int WH, bool FB>
-__global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : (Cfg<WW, WH>::TPL == 2 ? 3 : 2))) void k_lk_fast(LKJobs JJ, LKParams P)
+// Waves per SIMD the register allocation aims at: 21x21 needs 86 VGPRs (5 waves fit), 31x31 144 (3), 35x35 180 -- held to
+// 168 for a third wave at the price of 16 B of scratch: REF 654 -> 770 pairs/s.  Forcing more (21x21 at 8, 31x31 at 4) spills
+// into the loops and loses.
+__global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : 3)) void k_lk_fast(LKJobs JJ, LKParams P)
 {
     using C = Cfg<WW, WH>;
     __shared__ uint32_t lds[C::LDS_DW];

@@ -11,7 +11,12 @@ namespace lkf {
 
 using namespace lk;
 
-constexpr int kMargin = 6;  // search-tile margin R: the estimate may move +-R px before a restage
+// Search-tile margin R: the estimate may move +-R px from where the tile was staged before it is staged again.  Results
+// do not depend on it.  Measured (C2 / REF / C5 pairs/s): R = 6: 5 040 / 611 / 470; 3: 5 300 / 640 / 530; 2: 5 280 / 652 /
+// 547; 1: 5 360 / 654 / 552; 0: 5 240 / 645 / 534.  A level's first guess comes from the level above and lands within a
+// pixel of the answer, so a wide tile is loaded (and its addresses computed, and its registers held) for nothing; with
+// R = 1 the 21x21 search tile is 24x24 B = 3 rounds of loads instead of 6 (34x34).
+constexpr int kMargin = kLkTileMargin;
 
 constexpr int pick_seg(int ww, int wh)
 {
