@@ -145,6 +145,7 @@ struct Ctx {
     int staged_n = 0;
 
     int last_candidates = 0, last_accepted = 0;   // of the latest detection
+    double prune_factor = 8.0;                    // candidates kept per corner wanted (top-K pruning, detect_begin)
     DetectJob job{};
     size_t reset_ncell = 0;    // the detector counters are known to be zero for grids up to this many cells
     bool counters_clean = false;
@@ -735,11 +736,13 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
     J.quality = quality;
     J.min_distance = min_distance;
     J.ncell = ncell;
-    // top-K pruning (k_corners.hip): worthwhile when maxCorners is a real cap; 8x leaves a wide margin over the
-    // ~1 in 4 candidates that survive the minDistance rule, and detect_finish verifies it
+    // top-K pruning (k_corners.hip): worthwhile when maxCorners is a real cap.  Only the strongest candidates can be among
+    // the first maxCorners accepted ones; how many to keep follows the share that survived the minDistance rule in the
+    // detection before (with half as many again; 8x to begin with and after a shortfall), and detect_finish verifies
+    // that maxCorners corners came out -- else the stage runs once more on all candidates
     J.prune_want = 0;
     if (min_distance >= 1 && max_corners > 0 && max_corners <= (1 << 24) && !getenv("ICELK_NO_PRUNE"))
-        J.prune_want = 8 * max_corners;
+        J.prune_want = (int)std::min(8.0 * max_corners, std::ceil(c->prune_factor * max_corners));
     if (min_distance >= 1) {
         J.cand_count_ptr = D.cell_start + ncell;
         ProfScope p(c, K_SUPPRESS, ds);
@@ -777,8 +780,10 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
             return ICELK_OK;
         };
         if ((rc = converge())) return rc;
+        bool redone = false;
         if (J.prune_want > 0 && c->h_counts[3] && (max_corners <= 0 || c->h_counts[1] < max_corners)) {
             // the pruned candidate set did not yield maxCorners corners: redo the stage on all candidates
+            redone = true;
             launch_detect_reset(ds, D, (int)J.ncell, false);
             launch_min_distance(ds, D, J.w, J.h, J.min_distance, J.quality, 0);
             if ((rc = check_launch(c, "min_distance (unpruned)"))) return rc;
@@ -786,6 +791,12 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
             if ((rc = converge())) return rc;
         }
         total = c->h_counts[1];
+        if (J.prune_want > 0 && max_corners > 0) {
+            // next time: candidates per accepted corner as seen now, and half as many again; a detection that fell short
+            // (it was redone above) or was not pruned at all starts over at 8x
+            const bool fell_short = !c->h_counts[3] || redone;
+            c->prune_factor = fell_short || total <= 0 ? 8.0 : std::min(8.0, std::max(2.0, 1.5 * (double)c->h_counts[0] / total));
+        }
         c->last_candidates = c->h_counts[0];
         c->last_accepted = total;
         if (total == 0) return ICELK_OK;

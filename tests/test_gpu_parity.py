@@ -185,6 +185,28 @@ def test_good_features_exact(ctx, orc, synth, maxc, q, md, bs):
     assert np.array_equal(got, ref)
 
 
+def test_pruning_follows_the_survival_rate_and_stays_exact(orc, synth):
+    """With maxCorners a real cap only the strongest candidates enter the minDistance stage; how many follows the share
+    that survived in the detection before (8x maxCorners at first).  Whatever the history -- the same frame again, a
+    much larger minDistance right after a small one (the kept set falls short: the stage is redone on all candidates),
+    back again -- the corners are those of the oracle."""
+    from iceberg_tracking_code_amd import Context
+    w, h = 1000, 800
+    img = synth.frame(w, h, 30, -20, 77)
+    c = Context(w, h, n_slots=1, max_pts=8192)
+    c.upload_gray(0, img)
+    seen = []
+    for maxc, md in ((400, 5), (400, 5), (400, 5), (400, 60), (400, 60), (150, 5), (400, 5), (2000, 3), (2000, 3)):
+        got = c.good_features(0, maxc, 0.005, md, False, 5)
+        ref = orc.good_features(img, maxc, 0.005, md, None, 5)
+        assert got.shape == ref.shape and np.array_equal(got, ref), (maxc, md)
+        seen.append(c.detect_stats())
+    c.close()
+    # the kept set shrank after the first detection of a kind, and grew back where it had fallen short
+    assert seen[1]["candidates"] < seen[0]["candidates"] and seen[2]["candidates"] <= seen[1]["candidates"]
+    assert seen[3]["candidates"] > seen[2]["candidates"]
+
+
 def test_good_features_mask_and_none(ctx, orc, synth):
     img = synth.frame(640, 480, 0, 0, 4321)
     mask = np.zeros_like(img)
