@@ -316,11 +316,10 @@ def main():
         torch.cuda.synchronize()
 
     def run_resident(tracker, order, first, count):
-        """`count` steps over frames that sit in HBM; the slots of the next four frames are known to the tracker."""
+        """`count` steps over frames that sit in HBM; the slots of the next six frames are known to the tracker."""
         n = len(order)
         for i in range(first, first + count):
-            nxt = [order[i + k] if i + k < n else None for k in (1, 2, 3, 4)]
-            tracker.push_slot(order[i], wait=False, next_slot=nxt[0], next2_slot=nxt[1], next3_slot=nxt[2], next4_slot=nxt[3])
+            tracker.push_slot(order[i], False, *[order[i + k] if i + k < n else None for k in range(1, 7)])
 
     # ---- the timed region -------------------------------------------------------------------------------------------------
     order = list(range(ring)) if linear else ping_pong(ring, K + W)

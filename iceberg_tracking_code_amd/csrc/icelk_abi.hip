@@ -27,6 +27,7 @@ struct DetectJob {
     size_t ncell = 0;
     const int* cand_count_ptr = nullptr;
     int prune_want = 0;   // > 0: top-K pruning is on for this job
+    unsigned long long seq = 0;   // order of icelk_seg_detect_begin calls: the oldest job in flight is finished first
 };
 
 struct Ctx {
@@ -79,8 +80,27 @@ struct Ctx {
         int slot = -1, block_size = 0, use_mask = 0;
         unsigned long long gen = 0, mask_gen = 0;
         hipEvent_t done = nullptr;
-    } eo[2];
+    } eo[3];
     int eo_active = 0;
+    // Two detections may be in flight (begun, not finished): the min-distance stage of frame d+2 is issued before the
+    // host round trip of frame d, so that the round trip finds kernels that had a whole tracker launch to finish
+    // instead of standing in a serial loop with them.  The scratch of a detection (D, job, h_counts, the flags below,
+    // eo_active) exists twice; the members of this struct proper are the WORKING COPY of set `dset_cur`
+    // (det_load / det_save), which keeps every detector function written against one set.
+    struct DetSet {
+        DetectScratch D{};
+        DetectJob job{};
+        int* h_counts = nullptr;
+        hipEvent_t counts_ev = nullptr;   // h_counts holds the counts of this set's detection
+        hipEvent_t tail_done = nullptr;   // the tail of this set's latest detection (sort, emit, counter reset) is through
+        size_t reset_ncell = 0;
+        bool counters_clean = false;
+        int eo_active = 0;
+    } dset[2];
+    hipEvent_t counts_ev = nullptr, tail_done = nullptr;
+    hipStream_t tail_stream = nullptr;     // see detect_finish
+    int dset_cur = 0;
+    unsigned long long job_seq = 0;
     hipStream_t eig_stream = nullptr;
     unsigned long long mask_gen = 0;
 
@@ -483,6 +503,7 @@ static hipError_t create_side_streams(Ctx* c)
         hipError_t r = create_priority_stream(&c->det_stream);
         if (r == hipSuccess) r = create_priority_stream(&c->pyr_stream);
         if (r == hipSuccess) r = create_priority_stream(&c->eig_stream);
+        if (r == hipSuccess) r = create_priority_stream(&c->tail_stream);
         return r;
     }
     constexpr int NC = 8;
@@ -514,6 +535,8 @@ static hipError_t create_side_streams(Ctx* c)
         c->eig_stream = cand[e];
         const int q = pick([&](hipStream_t s) { return probe_pair(c->eig_stream, s, ea, eb) <= limit; });
         c->pyr_stream = cand[q];
+        const int t = pick([&](hipStream_t s) { return probe_pair(c->eig_stream, s, ea, eb) <= limit; });
+        c->tail_stream = cand[t];
         c->side_pick[0] = d;
         c->side_pick[1] = e;
         c->side_pick[2] = q;
@@ -529,6 +552,8 @@ static hipError_t create_side_streams(Ctx* c)
     if (eb) hipEventDestroy(eb);
     return r;
 }
+
+static void det_save(Ctx* c);
 
 static void destroy_ctx(Ctx* c)
 {
@@ -571,7 +596,26 @@ static void destroy_ctx(Ctx* c)
         if (e) hipEventDestroy(e);
     for (auto& e : c->eo)
         if (e.done) hipEventDestroy(e.done);
-    if (c->h_counts) hipHostFree(c->h_counts);
+    det_save(c);
+    for (auto& S : c->dset) {
+        if (S.h_counts) hipHostFree(S.h_counts);
+        if (S.counts_ev) hipEventDestroy(S.counts_ev);
+        if (S.tail_done) hipEventDestroy(S.tail_done);
+    }
+    {
+        DetectScratch& E = c->dset[c->dset_cur ^ 1].D;     // the other set's own arrays (the working copy's are freed below)
+        void* ep[] = {E.cand, E.cand_count, E.cell_count, E.cell_start, E.cell_fill, E.chunk_tot, E.cell_cand, E.state, E.undecided,
+                      E.acc, E.acc_sorted, E.acc_count, E.key_hist, E.prune_key, E.sort_tmp};
+        for (void* q : ep)
+            if (q) hipFree(q);
+    }
+    for (auto& e : c->eo) {   // [0] and [1] are in the list below
+        if (&e == &c->eo[2]) {
+            if (e.raw) hipFree(e.raw);
+            if (e.blk_count) hipFree(e.blk_count);
+            if (e.max_key) hipFree(e.max_key);
+        }
+    }
     if (c->h_seg) hipHostFree(c->h_seg);
     void* ptrs[] = {c->d_bgr, c->d_mask, c->d_p0, c->d_p1, c->d_p0r, c->d_err_f, c->d_err_b, c->d_dist, c->d_corners,
                     c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.cand, c->D.cand_count,
@@ -596,6 +640,10 @@ static void destroy_ctx(Ctx* c)
         hipStreamSynchronize(c->pyr_stream);
         hipStreamDestroy(c->pyr_stream);
     }
+    if (c->tail_stream) {
+        hipStreamSynchronize(c->tail_stream);
+        hipStreamDestroy(c->tail_stream);
+    }
     delete c;
 }
 
@@ -614,12 +662,92 @@ __global__ void k_publish_counts(const int* __restrict__ cand, const int* __rest
     __threadfence_system();
 }
 
-static int fetch_counts(Ctx* c)
+static void det_save(Ctx* c)
+{
+    Ctx::DetSet& S = c->dset[c->dset_cur];
+    S.D = c->D;
+    S.job = c->job;
+    S.h_counts = c->h_counts;
+    S.counts_ev = c->counts_ev;
+    S.tail_done = c->tail_done;
+    S.reset_ncell = c->reset_ncell;
+    S.counters_clean = c->counters_clean;
+    S.eo_active = c->eo_active;
+}
+
+static void det_load(Ctx* c, int k)
+{
+    det_save(c);
+    const Ctx::DetSet& S = c->dset[k];
+    c->D = S.D;
+    c->job = S.job;
+    c->h_counts = S.h_counts;
+    c->counts_ev = S.counts_ev;
+    c->tail_done = S.tail_done;
+    c->reset_ncell = S.reset_ncell;
+    c->counters_clean = S.counters_clean;
+    c->eo_active = S.eo_active;
+    c->dset_cur = k;
+}
+
+// the set of the oldest detection in flight, or -1
+static int det_oldest(Ctx* c)
+{
+    det_save(c);
+    int k = -1;
+    for (int i = 0; i < 2; i++)
+        if (c->dset[i].job.active && (k < 0 || c->dset[i].job.seq < c->dset[k].job.seq)) k = i;
+    return k;
+}
+
+// a set with no detection in flight, or -1
+static int det_free(Ctx* c)
+{
+    det_save(c);
+    for (int i = 0; i < 2; i++)
+        if (!c->dset[i].job.active) return i;
+    return -1;
+}
+
+// a candidate buffer no detection in flight reads: the one that holds what `want` asks for if there is one, else one
+// without valid content, else any
+static int eo_free(Ctx* c, const Ctx::EigOut* want)
+{
+    det_save(c);
+    bool busy[3] = {false, false, false};
+    for (int i = 0; i < 2; i++)
+        if (c->dset[i].job.active) busy[c->dset[i].eo_active] = true;
+    int pick = -1;
+    for (int i = 0; i < 3; i++) {
+        if (busy[i]) continue;
+        const Ctx::EigOut& e = c->eo[i];
+        if (want && e.valid && e.slot == want->slot && e.gen == want->gen && e.block_size == want->block_size &&
+            e.use_mask == want->use_mask && e.mask_gen == want->mask_gen)
+            return i;
+        if (pick < 0 || (c->eo[pick].valid && !e.valid)) pick = i;
+    }
+    return pick;
+}
+
+// The counts of the working set's detection go to its pinned host words behind whatever is queued on the detection
+// stream, and an event of the set marks them.  detect_begin ends with this, so the host round trip of that detection
+// waits for ITS kernels only -- not for the min-distance stage of the next detection that may be queued behind them.
+static int publish_counts(Ctx* c)
 {
     const DetectJob& J = c->job;
     hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(1), 0, c->det_stream, J.cand_count_ptr, c->D.acc_count,
                        c->D.undecided + suppress_launch_count() - 1, c->D.prune_key, c->h_counts);
-    HIPCHK(c, hipStreamSynchronize(c->det_stream));
+    HIPCHK(c, hipEventRecord(c->counts_ev, c->det_stream));
+    return ICELK_OK;
+}
+
+static int fetch_counts(Ctx* c, bool published = false)
+{
+    if (!published) {
+        int rc = publish_counts(c);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipEventSynchronize(c->counts_ev));
     return ICELK_OK;
 }
 
@@ -650,7 +778,13 @@ static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
         if (c->mask_w != s.w || c->mask_h != s.h) FAIL(c, ICELK_EARG, "mask size differs from the frame");
         mask = c->d_mask;
     }
-    Ctx::EigOut& e = c->eo[c->eo_active ^ 1];
+    Ctx::EigOut want;
+    want.slot = slot;
+    want.gen = s.gen;
+    want.block_size = block_size;
+    want.use_mask = use_mask;
+    want.mask_gen = c->mask_gen;
+    Ctx::EigOut& e = c->eo[eo_free(c, &want)];
     if (e.valid && e.slot == slot && e.gen == s.gen && e.block_size == block_size && e.use_mask == use_mask &&
         e.mask_gen == c->mask_gen)
         return ICELK_OK;   // already there
@@ -688,7 +822,11 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
     if (rc) return rc;
     if (!(quality > 0) || min_distance < 0 || block_size <= 0) FAIL(c, ICELK_EARG, "bad detector parameters");
     if (min_eig_lds_bytes(block_size) > 150 * 1024) FAIL(c, ICELK_EARG, "blockSize too large");
-    if (c->job.active) FAIL(c, ICELK_ESTATE, "a detection is already in flight");
+    {
+        const int k = det_free(c);
+        if (k < 0) FAIL(c, ICELK_ESTATE, "two detections are in flight already");
+        det_load(c, k);
+    }
     Slot& s = c->slots[slot];
     const hipStream_t ds = c->det_stream;
     const int w = s.w, h = s.h;
@@ -707,23 +845,37 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
     }
     // the frame must be in the slot (ingest on the compute or the copy stream) and the previous corner list
     // must have been consumed before this detection overwrites it; nothing else orders the two streams
+    // the frame must be in the slot, and the tail of this set's previous detection (it sorted this set's accepted keys and
+    // reset its counters on the tail stream) must be through
     if (int rcw = wait_event(c, ds, s.frame_ev)) return rcw;   // level 0 only (see detect_prepare)
-    if (int rcw = wait_event(c, ds, c->corners_free)) return rcw;
+    if (int rcw = wait_event(c, ds, c->tail_done)) return rcw;
     const bool generic = getenv("ICELK_GENERIC_CORNERS") != nullptr;
     // counters are normally left zeroed by the previous detection (the reset runs after its last kernel,
     // off the critical path); reset here only the first time or when the cell grid grew
     const bool need_reset = !c->counters_clean || ncell > c->reset_ncell;
-    Ctx::EigOut& spare = c->eo[c->eo_active ^ 1];
+    Ctx::EigOut want;
+    want.slot = slot;
+    want.gen = s.gen;
+    want.block_size = block_size;
+    want.use_mask = use_mask;
+    want.mask_gen = c->mask_gen;
+    const int spare_idx = eo_free(c, &want);
+    Ctx::EigOut& spare = c->eo[spare_idx];
     const bool prepared = spare.valid && spare.slot == slot && spare.gen == s.gen && spare.block_size == block_size &&
                           spare.use_mask == use_mask && spare.mask_gen == c->mask_gen && !generic;
-    spare.valid = false;   // adopted below, or stale: either way it is not offered again
+    spare.valid = false;   // adopted below, or overwritten: either way it is not offered again
     if (prepared) {
-        if (need_reset) launch_detect_reset(ds, D, (int)ncell, true);   // before the swap: the prepared maximum stays
-        activate_eig_out(c, c->eo_active ^ 1);
+        if (need_reset) launch_detect_reset(ds, D, (int)ncell, 1);
+        activate_eig_out(c, spare_idx);
         if (int rcw = wait_event(c, ds, spare.done)) return rcw;
     } else {
         ProfScope p(c, K_EIG, ds);
-        if (need_reset) launch_detect_reset(ds, D, (int)ncell, true);
+        // this detection's candidates go into a buffer no detection in flight reads; a prepare launch that wrote it
+        // (for another frame) must be through, and its maximum starts from zero
+        activate_eig_out(c, spare_idx);
+        if (int rcw = wait_event(c, ds, spare.done)) return rcw;
+        HIPCHK(c, hipMemsetAsync(spare.max_key, 0, sizeof(unsigned), ds));
+        if (need_reset) launch_detect_reset(ds, D, (int)ncell, 1);
         launch_candidates(ds, D, s.lv[0], block_size, mask, c->mask_pitch, quality, generic, nullptr);
         HIPCHK(c, hipEventRecord(s.det_used, ds));   // nothing after this launch reads the frame
     }
@@ -753,19 +905,30 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
     }
     rc = check_launch(c, "min_distance");
     if (rc) return rc;
+    rc = publish_counts(c);
+    if (rc) return rc;
     J.active = true;
+    J.seq = ++c->job_seq;
     return ICELK_OK;
 }
 
 static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
 {
+    {
+        const int k = det_oldest(c);
+        if (k < 0) FAIL(c, ICELK_ESTATE, "no detection in flight");
+        det_load(c, k);
+    }
     DetectJob& J = c->job;
-    if (!J.active) FAIL(c, ICELK_ESTATE, "no detection in flight");
     J.active = false;
     *n_out = 0;
     const hipStream_t ds = c->det_stream;
+    // Everything behind the host round trip -- sort, corner list, the reset of this set's counters, and in seg_stage the
+    // new segment's tables -- goes to the tail stream: the detection stream may already hold the min-distance stage of
+    // the NEXT detection (the other set), and the two have nothing in common but d_corners, which only tails touch.
+    const hipStream_t ts = c->tail_stream;
     DetectScratch& D = c->D;
-    int rc = fetch_counts(c);   // the one host round trip of a detection: {candidates, accepted, undecided}
+    int rc = fetch_counts(c, true);   // the one host round trip of a detection: {candidates, accepted, undecided}
     if (rc) return rc;
     const unsigned long long* sorted = nullptr;
     int total = 0;
@@ -784,7 +947,7 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
         if (J.prune_want > 0 && c->h_counts[3] && (max_corners <= 0 || c->h_counts[1] < max_corners)) {
             // the pruned candidate set did not yield maxCorners corners: redo the stage on all candidates
             redone = true;
-            launch_detect_reset(ds, D, (int)J.ncell, false);
+            launch_detect_reset(ds, D, (int)J.ncell, 0);
             launch_min_distance(ds, D, J.w, J.h, J.min_distance, J.quality, 0);
             if ((rc = check_launch(c, "min_distance (unpruned)"))) return rc;
             if ((rc = fetch_counts(c))) return rc;
@@ -800,14 +963,14 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
         c->last_candidates = c->h_counts[0];
         c->last_accepted = total;
         if (total == 0) return ICELK_OK;
-        sort_keys_desc(ds, D, D.acc, D.acc_sorted, total);
+        sort_keys_desc(ts, D, D.acc, D.acc_sorted, total);
         sorted = D.acc_sorted;
     } else {
         total = c->h_counts[0];
         c->last_candidates = total;
         c->last_accepted = total;
         if (total == 0) return ICELK_OK;
-        sort_keys_desc(ds, D, D.cand, D.cell_cand, total);
+        sort_keys_desc(ts, D, D.cand, D.cell_cand, total);
         sorted = D.cell_cand;
     }
     rc = check_launch(c, "sort");
@@ -816,13 +979,14 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
     if (max_corners > 0 && n > max_corners) n = max_corners;
     if (n > cap || n > c->max_pts) FAIL(c, ICELK_ECAP, "more corners than the output capacity (raise max_pts)");
     {
-        ProfScope p(c, K_EMIT, ds);
-        launch_emit_corners(ds, sorted, n, J.w, c->d_corners);
+        ProfScope p(c, K_EMIT, ts);
+        launch_emit_corners(ts, sorted, n, J.w, c->d_corners);
     }
     rc = check_launch(c, "emit");
     if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->det_done, ds));
-    launch_detect_reset(ds, D, (int)J.ncell, true);   // for the next detection
+    HIPCHK(c, hipEventRecord(c->det_done, ts));
+    launch_detect_reset(ts, D, (int)J.ncell, 1);   // for this set's next detection, which waits for tail_done
+    HIPCHK(c, hipEventRecord(c->tail_done, ts));
     c->reset_ncell = J.ncell;
     c->counters_clean = true;
     *n_out = n;
@@ -833,6 +997,8 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
                        int block_size, int cap, int* n_out)
 {
     *n_out = 0;
+    // begin + finish in one go: the detection finished must be the one begun here
+    if (det_oldest(c) >= 0) FAIL(c, ICELK_ESTATE, "a detection is in flight (icelk_seg_detect_begin without _stage / _finish)");
     int rc = detect_begin(c, slot, use_mask, max_corners, quality, min_distance, block_size);
     if (rc) return rc;
     return detect_finish(c, max_corners, cap, n_out);
@@ -1189,7 +1355,46 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         if (!strcmp(k, "generic")) c->lk_kernel_flags = ICELK_FLAG_GENERIC_KERNEL;
         else if (!strcmp(k, "multi")) c->lk_kernel_flags = ICELK_FLAG_MULTI_PER_WAVE;
     }
+    // the third candidate buffer, and the second detector set (everything a detection in flight owns; the full-frame
+    // eigenvalue map of icelk_min_eig_map is shared)
+    if ((rc = dmalloc(c, &c->eo[2].max_key, 1)) || (rc = dmalloc(c, &c->eo[2].raw, (size_t)D.cand_cap)) ||
+        (rc = dmalloc(c, &c->eo[2].blk_count, candidate_blocks(max_w, max_h) * 4)))
+        return fail(rc);
+    if (hipEventCreateWithFlags(&c->eo[2].done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->counts_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->tail_done, hipEventDisableTiming) != hipSuccess) {
+        c->err = "hipEventCreate failed";
+        return fail(ICELK_EHIP);
+    }
     activate_eig_out(c, 0);
+    det_save(c);                       // set 0 = what has been allocated so far
+    {
+        Ctx::DetSet& S = c->dset[1];
+        DetectScratch& E = S.D;
+        E = c->D;
+        E.cand = nullptr; E.cand_count = nullptr; E.cell_count = nullptr; E.cell_start = nullptr; E.cell_fill = nullptr;
+        E.chunk_tot = nullptr; E.cell_cand = nullptr; E.state = nullptr; E.undecided = nullptr; E.acc = nullptr;
+        E.acc_sorted = nullptr; E.acc_count = nullptr; E.key_hist = nullptr; E.prune_key = nullptr; E.sort_tmp = nullptr;
+        if ((rc = dmalloc(c, &E.cand, (size_t)D.cand_cap)) || (rc = dmalloc(c, &E.cand_count, 1)) ||
+            (rc = dmalloc(c, &E.cell_count, c->ncell_cap)) || (rc = dmalloc(c, &E.cell_start, c->ncell_cap)) ||
+            (rc = dmalloc(c, &E.cell_fill, c->ncell_cap)) || (rc = dmalloc(c, &E.chunk_tot, (c->ncell_cap / 2048 + 2) * 32)) ||
+            (rc = dmalloc(c, &E.cell_cand, (size_t)D.cand_cap)) || (rc = dmalloc(c, &E.state, (size_t)D.cand_cap)) ||
+            (rc = dmalloc(c, &E.undecided, 64)) || (rc = dmalloc(c, &E.acc, (size_t)D.cand_cap)) ||
+            (rc = dmalloc(c, &E.acc_sorted, (size_t)D.cand_cap)) || (rc = dmalloc(c, &E.acc_count, 1)) ||
+            (rc = dmalloc(c, &E.key_hist, 1 << 16)) || (rc = dmalloc(c, &E.prune_key, 1)) ||
+            (rc = dmalloc(c, (uint8_t**)&E.sort_tmp, D.sort_tmp_bytes)))
+            return fail(rc);
+        if (hipHostMalloc(reinterpret_cast<void**>(&S.h_counts), 64, hipHostMallocMapped) != hipSuccess ||
+            hipEventCreateWithFlags(&S.counts_ev, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming) != hipSuccess) {
+            c->err = "hipHostMalloc failed";
+            return fail(ICELK_EHIP);
+        }
+        S.eo_active = 1;
+        E.raw = c->eo[1].raw;
+        E.blk_count = c->eo[1].blk_count;
+        E.max_key = c->eo[1].max_key;
+    }
     if (hipMemset(c->d_tracked, 0, 64 * 8) != hipSuccess) {
         c->err = "hipMemset failed";
         return fail(ICELK_EHIP);
@@ -1229,6 +1434,7 @@ int icelk_sync(icelk_t* h)
     HIPCHK(c, hipStreamSynchronize(c->pyr_stream));
     HIPCHK(c, hipStreamSynchronize(c->eig_stream));
     HIPCHK(c, hipStreamSynchronize(c->det_stream));
+    HIPCHK(c, hipStreamSynchronize(c->tail_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ICELK_OK;
 }
@@ -1678,11 +1884,17 @@ int icelk_min_eig_map(icelk_t* h, int slot, int block_size, float* host_out, int
     if (min_eig_lds_bytes(block_size) > 150 * 1024) FAIL(c, ICELK_EARG, "blockSize too large");
     rc = wait_slot(c, slot);
     if (rc) return rc;
+    {
+        const int k = det_free(c);     // scratch of a set no detection in flight owns
+        if (k < 0) FAIL(c, ICELK_ESTATE, "two detections are in flight");
+        det_load(c, k);
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));       // the frame is in place
     HIPCHK(c, hipStreamSynchronize(c->det_stream));   // the detector scratch is free
+    HIPCHK(c, hipStreamSynchronize(c->tail_stream));
     {
         ProfScope p(c, K_EIG);
-        launch_detect_reset(c->stream, c->D, 0, true);
+        launch_detect_reset(c->stream, c->D, 0, 3);
         c->counters_clean = false;
         if (fused_block_size(block_size) && !getenv("ICELK_GENERIC_CORNERS")) {
             launch_candidates(c->stream, c->D, s.lv[0], block_size, nullptr, 0, 1.0, false, c->D.eig);
@@ -1709,8 +1921,8 @@ int icelk_good_features(icelk_t* h, int slot, int use_mask, int max_corners, dou
     int rc = detect_core(c, slot, use_mask, max_corners, quality_level, min_distance, block_size, cap, &n);
     if (rc) return rc;
     if (n > 0) {
-        HIPCHK(c, hipMemcpyAsync(out_xy, c->d_corners, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->det_stream));
-        HIPCHK(c, hipStreamSynchronize(c->det_stream));
+        HIPCHK(c, hipMemcpyAsync(out_xy, c->d_corners, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->tail_stream));
+        HIPCHK(c, hipStreamSynchronize(c->tail_stream));
     }
     *out_n = n;
     return ICELK_OK;
@@ -1752,10 +1964,10 @@ static int seg_stage(Ctx* c, int max_corners, int* out_n)
     int n = 0;
     int rc = detect_finish(c, max_corners, c->max_pts, &n);
     if (rc) return rc;
-    // the new segment goes into the other set, on the detection stream right behind the corner list; launches
-    // that still touch that set (the segment before the closing one) must be through
+    // the new segment goes into the set after the current one, on the tail stream right behind the corner list; launches
+    // that still touch that set (a segment closed two switches ago) must be through
     Ctx::SegBuf& nb = c->sb[(c->sb_cur + 1) % kSegSets];
-    const hipStream_t ds = c->det_stream;
+    const hipStream_t ds = c->tail_stream;
     if (int rcw = wait_event(c, ds, nb.used)) return rcw;
     launch_seg_init(ds, c->d_corners, n, nb.live, nb.alive, nb.tracks, kMaxVert);
     if (c->use_order) launch_seg_order(ds, c->d_corners, n, c->job.w, c->job.h, c->border_px, nb.order, nb.order_border);

@@ -159,7 +159,9 @@ struct DetectScratch {
 void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig, const uint8_t* mask,
                     int mask_pitch, unsigned* max_key);
 bool fused_block_size(int bs);
-void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, bool full);   // full: before launch_candidates
+// mode: 0 = the cell grid and the counters; | 1 = the key histogram too; | 2 = and the masked maximum D.max_key (only where
+// the candidate buffer behind it is known to be this detection's: it may have been handed on since)
+void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, int mode);
 // K6+K7: local maxima into per-workgroup regions of D.raw (stream order, no host sync)
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
                        int mask_pitch, double quality, bool use_generic, float* eig_out_or_null);

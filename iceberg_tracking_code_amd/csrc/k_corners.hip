@@ -758,14 +758,14 @@ __global__ void k_detect_reset(int* __restrict__ cell_count, int* __restrict__ c
         if (i < ncell) cell_fill[i] = 0;
         if (i % SCAN_CHUNK == 0) chunk_tot[(i / SCAN_CHUNK) * CHUNK_TOT_STRIDE] = 0;
     }
-    if (full)
+    if (full & 1)
         for (int i = i0; i < KEY_BINS; i += gridDim.x * blockDim.x) key_hist[i] = 0;
     if (i0 < 8) undecided[i0] = 0;
     if (i0 == 0) {
         *acc_count = 0;
         *cand_count = 0;
         *prune_key = 0;
-        if (full) *max_key = 0;
+        if (full & 2) *max_key = 0;
     }
 }
 
@@ -873,13 +873,13 @@ static CandSrc src_of(const DetectScratch& D)
 // First launch of every detection: zero the counters (ncell = 0 when minDistance < 1).
 // full = also the response maximum and the key histogram (i.e. everything a NEW detection needs); !full = only
 // what a re-run of the min-distance stage on the same candidates needs.
-void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, bool full)
+void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, int mode)
 {
     int blocks = (ncell + CT) / CT;
-    if (full && blocks < KEY_BINS / CT) blocks = KEY_BINS / CT;
+    if ((mode & 1) && blocks < KEY_BINS / CT) blocks = KEY_BINS / CT;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_detect_reset, dim3(blocks), dim3(CT), 0, s, D.cell_count, D.cell_fill, ncell, D.chunk_tot, D.undecided,
-                       D.acc_count, D.cand_count, D.max_key, D.key_hist, D.prune_key, full ? 1 : 0);
+                       D.acc_count, D.cand_count, D.max_key, D.key_hist, D.prune_key, mode);
 }
 
 // Candidate collection (K6+K7) into regions of D.raw (stream order, no host sync).

@@ -180,15 +180,14 @@ class SegmentTracker:
         self.pair_launch = bool(pair_launch) and self.lookahead   # see `_step`: joint launch across a segment change
         self._pyr_ahead = set()   # slots whose pyramid was enqueued ahead of their step
         # how many steps ahead of a detection frame its min-distance stage / its corner candidates may start (`_step`)
-        self.begin_ahead, self.prepare_ahead = 3, 4
+        self.begin_ahead, self.prepare_ahead, self.stage_lag = 4, 6, 2
         self._resident = False    # inside push_slot
         # callable(first_frame, closed) invoked once per finished segment, when all its pairs have been launched: e.g.
         # ctx.seg_archive(..., closed=closed).  closed=False: the segment is still the current one (the switch follows);
         # closed=True: the switch has happened (its last pair went out in a joint launch, see `_step`)
         self.on_close = None
         self._advanced = False    # the pair (cur, next) has gone out already, with the joint launch of this step
-        self._det_for = None      # frame counter whose detection (min-distance stage) is in flight
-        self._det_begun = -1      # ... and the step at which it was begun
+        self._det_queue = []      # detections in flight, oldest first: (frame counter, step at which it was begun)
         self._begun_upto = -1     # latest frame whose detection has been begun
         self._prep_upto = -1      # latest frame whose corner candidates have been prepared ahead
         self._staged = False      # a new segment waits in the spare set for the switch
@@ -238,16 +237,17 @@ class SegmentTracker:
             raise RuntimeError("no prefetched frame")
         s = self._prefetched.pop(0)
         q = self._prefetched
-        return self._step(s, wait, *[q[k] if len(q) > k else None for k in range(4)])
+        return self._step(s, wait, *q[:self.MAX_AHEAD])
 
-    def push_slot(self, slot, wait=True, next_slot=None, next2_slot=None, next3_slot=None, next4_slot=None):
+    def push_slot(self, slot, wait=True, *ahead):
         """Use a frame that already sits in `slot` (level 0 resident in HBM); its pyramid is rebuilt.
-        `next_slot` .. `next4_slot`: where the following frames already sit, if they do (see `_step`)."""
+        `ahead`: the slots where the following frames already sit, nearest first, up to MAX_AHEAD of them (see `_step`);
+        None ends the list."""
         if slot not in self._pyr_ahead:
             self.ctx.drop_pyramid(slot)
         self._resident = True
         try:
-            return self._step(slot, wait, next_slot, next2_slot, next3_slot, next4_slot)
+            return self._step(slot, wait, *ahead)
         finally:
             self._resident = False
 
@@ -261,18 +261,21 @@ class SegmentTracker:
         self.ctx.seg_detect_begin(slot, self.fp["maxCorners"], self.fp["qualityLevel"], self.fp["minDistance"],
                                   self.use_mask, self.fp.get("blockSize", 3))
 
-    def _step(self, slot, wait, next_slot=None, next2_slot=None, next3_slot=None, next4_slot=None):
-        """One pass of the loop body.  `next_slot` .. `next4_slot`: slots of the FOLLOWING frames when they are already
-        on their way to the device (prefetched uploads, resident ring).  The detector needs nothing but its own frame,
-        so the work for a coming detection frame d is spread over the steps before it and runs beside their tracker
-        launches, each part as early as the frame's slot is known and the buffers it needs are free:
-          d-4  corner candidates (`seg_detect_prepare`: spare candidate buffer, own stream)
-          d-3  min-distance stage (`seg_detect_begin`)
+    MAX_AHEAD = 6
+
+    def _step(self, slot, wait, *ahead_slots):
+        """One pass of the loop body.  `ahead_slots`: slots of the FOLLOWING frames (nearest first, up to six) when they
+        are already on their way to the device (prefetched uploads, resident ring).  The detector needs nothing but its
+        own frame, so the work for a coming detection frame d is spread over the steps before it and runs beside their
+        tracker launches, each part as early as the frame's slot is known and the buffers it needs are free:
+          d-6  corner candidates (`seg_detect_prepare`: a spare candidate buffer, own stream)
+          d-4  min-distance stage (`seg_detect_begin`) -- two detections may be in flight
           d-2  the one host round trip of a detection, the sort and the new segment's initialisation in the spare set
-               of segment buffers (`seg_detect_stage`) -- issued BEHIND the tracker launch of that step, and waiting
-               for kernels that had a whole step to finish: the host never stands between two tracker launches
+               of segment buffers (`seg_detect_stage`): it waits for kernels that were issued two steps -- with
+               track_len 2 a whole tracker launch -- earlier, and the min-distance stage of the NEXT detection is on
+               the device already, so the host never stands in a loop with the detector's kernels
           d    the switch (no GPU work, no wait).
-        With less lookahead the same calls move later, each at least one step after the one before; with none,
+        With less lookahead the same calls move later (a stage one step after its begin at the least); with none,
         everything happens at d.
 
         Joint launch: the last pair of the closing segment, (d-1, d), and the first pair of the new one, (d, d+1), are
@@ -289,14 +292,20 @@ class SegmentTracker:
         bs = self.fp.get("blockSize", 3)
         lk_tail = (self.lk["winSize"], self.lk["maxLevel"], self.lk["criteria"], self.lk.get("minEigThreshold", 1e-4),
                    self.fb_threshold)
-        slot_of = {0: slot, 1: next_slot, 2: next2_slot, 3: next3_slot, 4: next4_slot}
+        slot_of = {0: slot}
+        for k, s_k in enumerate(ahead_slots[:self.MAX_AHEAD]):
+            if s_k is None:
+                break
+            slot_of[k + 1] = s_k
+        next_slot, next2_slot = slot_of.get(1), slot_of.get(2)
         self._pyr_ahead.discard(slot)
         staged_now = self._staged and self._staged_for == c
-        if detect and not staged_now and self._det_for != c:
+        if detect and not staged_now and not (self._det_queue and self._det_queue[0][0] == c):
             # nothing was started ahead for this detection frame: start it now, on its own stream, so that it runs
             # beside the tracker launch below (the reference does them back to back, s1:323-326 then s1:437)
             self._detect_begin(slot)
-            self._det_for, self._det_begun, self._begun_upto = c, c, c
+            self._det_queue.append((c, c))
+            self._begun_upto = c
         joint = False
         if self._advanced:
             self._advanced = False            # the pair (prev, slot) went out with the launch of the previous step
@@ -335,30 +344,33 @@ class SegmentTracker:
                 self.n_detected = self._staged_n
                 self._staged = False
             else:
-                self.n_detected = self.ctx.seg_detect_finish(self.fp["maxCorners"])
-                self._det_for = None
+                self.n_detected = self.ctx.seg_detect_finish(self.fp["maxCorners"])   # the oldest in flight: frame c's
+                self._det_queue.pop(0)
             self.active = True
             self.seg_first = c
         if ahead:
-            # corner candidates of the detection frame after the one begun last, up to four steps ahead, once the spare
-            # candidate buffer is free (the candidates prepared before have been adopted by their seg_detect_begin);
-            # first, so that the kernel is on the device before the host waits below
+            # the oldest detection in flight: its host round trip, and the new segment into the spare set (behind this
+            # step's switch, if there was one: the spare set is the one after the current) -- once its kernels have had
+            # `stage_lag` steps, or when its frame is next
+            if self._det_queue and not self._staged:
+                d, begun = self._det_queue[0]
+                if d > c and begun < c and (c - begun >= self.stage_lag or d - c <= 1):
+                    self._staged_n = self.ctx.seg_detect_stage(self.fp["maxCorners"])
+                    self._staged, self._staged_for = True, d
+                    self._det_queue.pop(0)
+            # min-distance stage of the next detection frame not begun yet: up to `begin_ahead` steps ahead, two
+            # detections in flight at most
+            d = max(self._begun_upto, c) // T * T + T
+            if len(self._det_queue) < 2 and 1 <= d - c <= self.begin_ahead and slot_of.get(d - c) is not None:
+                self._detect_begin(slot_of[d - c])
+                self._det_queue.append((d, c))
+                self._begun_upto = d
+            # corner candidates of the detection frame after the one begun last, once the frame's slot is known (six steps
+            # ahead at most) and the candidates prepared before have been adopted by their seg_detect_begin
             d = max(self._begun_upto, self._prep_upto, c) // T * T + T
-            if self._prep_upto <= self._begun_upto and 1 <= d - c <= self.prepare_ahead and slot_of[d - c] is not None:
+            if self._prep_upto <= self._begun_upto and 1 <= d - c <= self.prepare_ahead and slot_of.get(d - c) is not None:
                 self.ctx.seg_detect_prepare(slot_of[d - c], self.use_mask, bs)
                 self._prep_upto = d
-            # the detection in flight, begun at an earlier step: its host round trip, and the new segment into the spare
-            # set (behind this step's switch, if there was one: the spare set is the one after the current)
-            if self._det_for is not None and self._det_for > c and self._det_begun < c and not self._staged:
-                self._staged_n = self.ctx.seg_detect_stage(self.fp["maxCorners"])
-                self._staged, self._staged_for = True, self._det_for
-                self._det_for = None
-            # min-distance stage of the next detection frame, up to three steps ahead
-            d = (self._begun_upto // T + 1) * T if self._begun_upto >= 0 else 0
-            d = max(d, (c // T + 1) * T)
-            if self._det_for is None and 1 <= d - c <= self.begin_ahead and slot_of[d - c] is not None:
-                self._detect_begin(slot_of[d - c])
-                self._det_for, self._det_begun, self._begun_upto = d, c, d
         self.cur = slot
         self.counter += 1
         return out

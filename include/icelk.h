@@ -167,7 +167,10 @@ int icelk_seg_detect(icelk_t* h, int slot, int use_mask, int max_corners, double
                      double min_distance, int block_size, int* out_n);
 /* The same detection split in two, for pipelined loops: _begin enqueues the detector on the handle's
  * detection stream (it needs the frame only, so it overlaps a tracker launch issued after it) and returns
- * at once; _finish waits for it and starts the new segment. */
+ * at once; _finish waits for it and starts the new segment.  TWO detections may be in flight (a third _begin returns
+ * ICELK_ESTATE); _finish / _stage take them in the order they were begun and wait for the kernels of that one only.
+ * Beginning the detection of frame d+2 before staging the one of frame d lets the host round trip of a detection find
+ * kernels that had a whole tracker launch to finish, instead of standing in a serial loop with them. */
 int icelk_seg_detect_begin(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level,
                            double min_distance, int block_size);
 int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n);

@@ -149,7 +149,7 @@ def test_prefetched_uploads_equal_blocking_upload(synth, track_len):
 
 
 @pytest.mark.parametrize("track_len", [2, 3, 4])
-@pytest.mark.parametrize("depth", [1, 2, 3, 4])
+@pytest.mark.parametrize("depth", [1, 2, 3, 4, 6])
 def test_resident_ring_with_lookahead_equals_serial_loop(synth, track_len, depth):
     """Frames resident in HBM (bench.py's source): with the next 1 .. 4 slots known, the work of a coming detection
     frame moves ahead of it (candidates c-4, min-distance c-3, the host round trip + the new segment's initialisation in
@@ -169,7 +169,7 @@ def test_resident_ring_with_lookahead_equals_serial_loop(synth, track_len, depth
     trk = SegmentTracker(w, h, track_len, fp, lk, ctx=ctx)
     got = []
     for i in range(n):
-        nxt = [i + k if (i + k < n and k <= depth) else None for k in (1, 2, 3, 4)]
+        nxt = [i + k if (i + k < n and k <= depth) else None for k in range(1, 7)]
         s = trk.push_slot(i, True, *nxt)
         if s is not None:
             got.append(s)
@@ -216,7 +216,7 @@ def test_joint_launch_across_segment_change_equals_serial_loop(synth, track_len,
         for i, f in enumerate(frames):
             ctx.upload_gray(i, f)
         for i in range(n):
-            nxt = [i + k if i + k < n else None for k in (1, 2, 3, 4)]
+            nxt = [i + k if i + k < n else None for k in range(1, 7)]
             assert trk.push_slot(i, False, *nxt) is None
     elif source == "push":
         for f in frames:

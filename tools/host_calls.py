@@ -40,7 +40,7 @@ fp = dict(maxCorners=10000, qualityLevel=0.007, minDistance=10, blockSize=10)
 lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
 trk = SegmentTracker(w, h, 2, feature_params=fp, lk_params=lk, ctx=Logged(ctx))
 o, i, d = [], 0, 1
-for _ in range(K + 8):
+for _ in range(K + 12):
     o.append(i)
     if i + d < 0 or i + d >= ring:
         d = -d
@@ -70,7 +70,7 @@ for k in range(K):
         trk.prefetch_pinned(pinned[o[k + depth]], w)
         trk.push_prefetched(wait=False)
     else:
-        trk.push_slot(o[k], False, o[k + 1], o[k + 2], o[k + 3], o[k + 4])
+        trk.push_slot(o[k], False, *o[k + 1:k + 7])
 ctx.sync()
 el = time.perf_counter() - t0
 first = marks[40][1]

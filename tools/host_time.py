@@ -29,7 +29,7 @@ t = np.zeros(K)
 t0 = time.perf_counter()
 for k in range(K):
     a = time.perf_counter()
-    trk.push_slot(o[k], wait=False, next_slot=o[k + 1], next2_slot=o[k + 2], next3_slot=o[k + 3])
+    trk.push_slot(o[k], False, *o[k + 1:k + 7])
     t[k] = time.perf_counter() - a
 ctx.sync()
 el = time.perf_counter() - t0
