@@ -245,7 +245,7 @@ def main():
                     help="leave out the per-kernel HIP events (and with them the roofline object): shows what they cost")
     ap.add_argument("--time-all-kernels", action="store_true",
                     help="HIP-event timing of every kernel inside the timed region (default: the tracker launches only)")
-    ap.add_argument("--pcie-depth", type=int, default=4, help="c3: uploads in flight ahead of the tracker in the PCIe-inclusive run")
+    ap.add_argument("--pcie-depth", type=int, default=6, help="c3: uploads in flight ahead of the tracker in the PCIe-inclusive run")
     ap.add_argument("--pcie-spare-slots", type=int, default=6, help="c3: slots beyond the uploads in flight (previous + current + spares)")
     ap.add_argument("--no-pair-launch", action="store_true",
                     help="A/B: the last pair of a segment is launched on its own instead of with the first pair of the next")

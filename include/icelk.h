@@ -11,13 +11,13 @@
  *   - the caller owns every host buffer; the library owns all device memory (frames, pyramids, points).
  *   - a handle is bound to one GPU and is not thread-safe; use one handle per thread/process.
  *     Multi-GPU = one process per GPU, one handle each (DESIGN.md "Multi-GPU").
- *   - a handle owns FIVE HIP streams: compute (tracker launches, segment bookkeeping; replaceable by the
- *     caller's stream, icelk_set_stream), copy (icelk_upload_gray_async), pyramid (icelk_build_pyramid_ahead),
- *     detection (min-distance stage, sort, corner list, the new segment's tables)
- *     and candidates (the corner kernel of icelk_seg_detect_prepare).  They are ordered against each other by
- *     events inside the library; a call whose outputs are host buffers has finished with them when it returns.
- *     icelk_sync waits for ALL of them (and launches a pair held back by icelk_seg_track_defer first): after it
- *     nothing of the handle reads or writes any slot, mask or point buffer.
+ *   - a handle owns SEVEN HIP streams: compute (tracker launches, segment bookkeeping; replaceable by the
+ *     caller's stream, icelk_set_stream), two copy streams (icelk_upload_gray_async alternates between them), pyramid
+ *     (icelk_build_pyramid_ahead), detection (min-distance stage), tail (what follows a detection's host round trip:
+ *     sort, corner list, the new segment's tables) and candidates (the corner kernel of icelk_seg_detect_prepare).
+ *     They are ordered against each other by events inside the library; a call whose outputs are host buffers has
+ *     finished with them when it returns.  icelk_sync waits for ALL of them (and launches a pair held back by
+ *     icelk_seg_track_defer first): after it nothing of the handle reads or writes any slot, mask or point buffer.
  *   - "slot" = a device-resident frame with its Gaussian pyramid.  Slots let the caller keep the
  *     previous frame (prev_gray = frame_gray, s1:450) and its pyramid on the GPU instead of
  *     rebuilding both pyramids in every cv2.calcOpticalFlowPyrLK call as OpenCV does.
