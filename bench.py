@@ -614,6 +614,17 @@ def main():
                         "valu_busy_pct": pj.get("lk_fb_valu_busy_pct"), "lds_bank_conflict_ratio": pj.get("lk_fb_lds_bank_conflict_ratio"),
                         "waves_per_simd": pj.get("lk_fb_waves_per_simd"), "vgprs": pj.get("lk_fb_vgprs"),
                         "sgpr_spills": pj.get("lk_fb_sgpr_spills")}
+                    bes = pj.get("beside_valu_insts_per_launch")
+                    if bes and bes.get("k_eig_nms") and cname in ("c2", "c3", "c4") and lkp["pairs_per_launch"] > 1.5:
+                        # everything the SIMDs issue per period of the pipeline (two frames: one joint tracker launch,
+                        # one corner kernel, two pyramids, one min-distance chain) against the wall time of that period
+                        per_period = vi + bes["k_eig_nms"] + 2 * (bes.get("k_pyramid_ahead") or 0) + (bes.get("min_distance_chain") or 0)
+                        period_s = lkp["pairs_per_launch"] / out["value"]
+                        out["roofline"]["valu_issue"]["pipeline"] = {
+                            "wave_instructions_per_period": per_period, "period_us": period_s * 1e6,
+                            "achieved_per_s": per_period / period_s,
+                            "frac": {k: per_period / period_s / (SIMDS * CLOCK_HZ / v) for k, v in cyc.items()},
+                            "note": "tracker + corner kernel + pyramids + min-distance chain share the SIMDs: the pipeline as a whole is at the issue limit"}
             except Exception as exc:
                 sys.stderr.write("profiles/pmc_%s.json unreadable: %s\n" % (cname, exc))
         if world == 1 and not args.no_cpu_baseline:

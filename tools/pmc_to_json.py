@@ -53,6 +53,14 @@ if lk.get("GRBM_GUI_ACTIVE") and lk.get("SQ_ACTIVE_INST_VALU"):
     # gfx9 VALUBusy: quad-cycles of VALU issue summed over the SIMDs x 4 / (1024 SIMDs x GPU-active cycles); GRBM_GUI_ACTIVE
     # is the sum over the 8 XCDs
     out["lk_fb_valu_busy_pct"] = 100.0 * lk["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * lk["GRBM_GUI_ACTIVE"] / 8.0)
+# the kernels that run beside the tracker launch, per launch: with the tracker's they make up what the SIMDs issue per
+# period of the pipeline (one joint tracker launch, one corner kernel, two pyramids, one min-distance chain per two frames)
+def insts(prefix):
+    b = next((v for k, v in blocks.items() if k.startswith(prefix) and "workgroups" not in k), None)
+    return b.get("SQ_INSTS_VALU") if b else None
+out["beside_valu_insts_per_launch"] = {"k_eig_nms": insts("k_eig_nms"), "k_pyramid_ahead": insts("k_pyramid<3, 64, 64>"),
+                                       "min_distance_chain": sum(insts(k) or 0 for k in ("k_key_hist", "k_key_select", "k_cell_count", "k_scan",
+                                                                 "k_cell_fill", "k_suppress", "k_gather_accepted", "k_seg_order", "k_seg_init"))}
 res = json.load(open("profiles/r02_lk_resources.json"))
 out.update(lk_fb_vgprs=res["k_lk_fast<21,21,true>"]["vgprs"], lk_fb_waves_per_simd=res["k_lk_fast<21,21,true>"]["waves_per_simd"],
            lk_fb_sgpr_spills=res["k_lk_fast<21,21,true>"]["sgpr_spills"])
