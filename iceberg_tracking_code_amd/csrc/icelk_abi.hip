@@ -1028,10 +1028,10 @@ static LKJob seg_job(Ctx* c, int set, const Slot& s0, const Slot& s1, const LKPa
     if (primary) {
         B.p_fwd = c->d_p1;
         B.st_fwd = c->d_st_f;
-        B.err_fwd = c->d_err_f;
         B.p_bwd = c->d_p0r;
         B.st_bwd = c->d_st_b;
-        B.err_bwd = c->d_err_b;
+        // no err_fwd / err_bwd: the segment loop has no use for the residual error (s1:323,326 drop it), and the tracker
+        // kernels skip forming it when nobody takes it
         B.dist = c->d_dist;
         B.valid = c->d_valid;
     }
@@ -1705,7 +1705,7 @@ int icelk_pyrlk(icelk_t* h, int prev_slot, int next_slot, const float* prev_xy, 
     B.p_in = c->d_p0;
     B.p_fwd = c->d_p1;
     B.st_fwd = c->d_st_f;
-    B.err_fwd = c->d_err_f;
+    B.err_fwd = err ? c->d_err_f : nullptr;
     if (c->prof) { B.iters = c->d_iters; c->iters_n = n; }
     {
         ProfScope p(c, K_LK);
@@ -1751,10 +1751,10 @@ int icelk_track_fb(icelk_t* h, int slot0, int slot1, const float* p0, int n, int
     B.p_in = c->d_p0;
     B.p_fwd = c->d_p1;
     B.st_fwd = c->d_st_f;
-    B.err_fwd = c->d_err_f;
+    B.err_fwd = err_fwd ? c->d_err_f : nullptr;   // the residual error is only formed for a caller that takes it
     B.p_bwd = c->d_p0r;
     B.st_bwd = c->d_st_b;
-    B.err_bwd = c->d_err_b;
+    B.err_bwd = err_bwd ? c->d_err_b : nullptr;
     B.dist = c->d_dist;
     B.valid = c->d_valid;
     if (c->prof) { B.iters = c->d_iters; c->iters_n = n; }

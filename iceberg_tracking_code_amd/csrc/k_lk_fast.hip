@@ -39,7 +39,8 @@ __device__ __forceinline__ float sum_to_float(long long t)
 
 template <int WW, int WH>
 __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const Pyramid& PJ, float p0x, float p0y,
-                                                        const LKParams& P, uint32_t* ldsI, uint32_t* ldsJ, int lane)
+                                                        const LKParams& P, uint32_t* ldsI, uint32_t* ldsJ, int lane,
+                                                        bool want_err)
 {
     using C = Cfg<WW, WH>;
     constexpr int S = C::S;
@@ -199,6 +200,9 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
                 Rz.status = 0;
                 continue;
             }
+            // the mean absolute residual itself is only formed for a caller that takes it (the segment loop does not:
+            // s1:323 drops `err`): one more search-tile check, 7 bilinear samples per lane and a wave sum saved
+            if (!want_err) continue;
             if (!staged || !tile_covers(jx0, jy0, iqx, iqy)) {
                 jx0 = iqx - R; jy0 = iqy - R;
                 __syncthreads();
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : 3)) void k_lk_fast
     uint32_t* ldsJ = lds + C::I_DW;
     const float p0x = B.p_in[2 * f], p0y = B.p_in[2 * f + 1];
     if (lane == 0) stamp(B, 0);
-    const TrackResult r1 = track_point_fast<WW, WH>(J.I, J.J, p0x, p0y, P, ldsI, ldsJ, lane);
+    const TrackResult r1 = track_point_fast<WW, WH>(J.I, J.J, p0x, p0y, P, ldsI, ldsJ, lane, B.err_fwd != nullptr);
     if (lane == 0) {
         if (B.p_fwd) { B.p_fwd[2 * f] = r1.x; B.p_fwd[2 * f + 1] = r1.y; }
         if (B.st_fwd) B.st_fwd[f] = (uint8_t)r1.status;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : 3)) void k_lk_fast
         if (B.iters && !FB) B.iters[f] = (uint32_t)r1.iters;
     }
     if (FB) {
-        const TrackResult r2 = track_point_fast<WW, WH>(J.J, J.I, r1.x, r1.y, P, ldsI, ldsJ, lane);
+        const TrackResult r2 = track_point_fast<WW, WH>(J.J, J.I, r1.x, r1.y, P, ldsI, ldsJ, lane, B.err_bwd != nullptr);
         if (lane == 0) {
             if (B.p_bwd) { B.p_bwd[2 * f] = r2.x; B.p_bwd[2 * f + 1] = r2.y; }
             if (B.st_bwd) B.st_bwd[f] = (uint8_t)r2.status;
