@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Tracker launch time against pyramid depth (maxLevel 0..3) at 1 and 2 forced iterations per level: per-workgroup
-constant (wave start, table look-ups, epilogue), per-level-pass fixed part, per-iteration part.  20 000 features."""
+constant (wave start, table look-ups, epilogue), per-level-pass fixed part, per-iteration part.  argv: features (20 000)."""
 import os
 import sys
 
@@ -16,7 +16,8 @@ ctx = Context(w, h, n_slots=2, max_pts=1 << 16)
 sh = synth.shifts(3, seed=1234)
 ctx.synth_frame(0, w, h, int(sh[1, 0]), int(sh[1, 1]), 1234)
 ctx.synth_frame(1, w, h, int(sh[2, 0]), int(sh[2, 1]), 1234)
-pts = ctx.good_features(0, 20000, 0.007, 10, False, 10).reshape(-1, 2)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+pts = ctx.good_features(0, N, 0.007, 10 if N <= 20000 else 5, False, 10).reshape(-1, 2)
 n = len(pts)
 ctx.track_fb(0, 1, pts[:1000], win, 3)
 res = {}
