@@ -189,7 +189,7 @@ def _serial_segments(frames, w, h, track_len, fp, lk):
     return want
 
 
-@pytest.mark.parametrize("source", ["resident", "push", "prefetch"])
+@pytest.mark.parametrize("source", ["resident", "push", "prefetch", "prefetch6"])
 @pytest.mark.parametrize("track_len", [1, 2, 3])
 def test_joint_launch_across_segment_change_equals_serial_loop(synth, track_len, source):
     """With no read-out at the detection frame (wait=False) and the following frame already on the device, the last
@@ -203,7 +203,7 @@ def test_joint_launch_across_segment_change_equals_serial_loop(synth, track_len,
     fp = dict(maxCorners=300, qualityLevel=0.007, minDistance=10, blockSize=10)
     lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
     want = _serial_segments(frames, w, h, track_len, fp, lk)
-    ctx = Context(w, h, n_slots={"resident": n, "push": 3, "prefetch": 5}[source], max_pts=4096)
+    ctx = Context(w, h, n_slots={"resident": n, "push": 3, "prefetch": 5, "prefetch6": 9}[source], max_pts=4096)
     trk = SegmentTracker(w, h, track_len, fp, lk, ctx=ctx)
     got = []
 
@@ -227,16 +227,17 @@ def test_joint_launch_across_segment_change_equals_serial_loop(synth, track_len,
             p = ctx.host_alloc(w * h)
             C.memmove(p, f.ctypes.data, w * h)
             ptrs.append(p)
-        trk.prefetch_pinned(ptrs[0], w)
-        trk.prefetch_pinned(ptrs[1], w)
+        depth = 6 if source == "prefetch6" else 2      # uploads in flight ahead of the frame being tracked
+        for i in range(min(depth, n)):
+            trk.prefetch_pinned(ptrs[i], w)
         for i in range(n):
-            if i + 2 < n:
-                trk.prefetch_pinned(ptrs[i + 2], w)
+            if i + depth < n:
+                trk.prefetch_pinned(ptrs[i + depth], w)
             assert trk.push_prefetched(wait=False) is None
     trk.flush()
     ctx.sync()
     prof = ctx.prof_table()
-    if source == "prefetch":
+    if source.startswith("prefetch"):
         for p in ptrs:
             ctx.host_free(p)
     trk.close()
@@ -294,6 +295,45 @@ def test_waiting_pair_goes_out_when_its_result_is_needed(synth):
         assert launches() == 1
         assert np.array_equal(t, want_t) and np.array_equal(q, want_q) and len(t) > 150
     ctx.close()
+
+
+def test_two_detections_in_flight(synth):
+    """Two detections may be begun before the first is staged (second detector scratch set, third candidate buffer); a
+    third _begin, or a one-call detection in between, is refused (ICELK_ESTATE); _stage / _finish take them in the order
+    they were begun, and each gives the corners a detection on its own gives -- with and without prepared candidates."""
+    from iceberg_tracking_code_amd import Context
+    from iceberg_tracking_code_amd._lib import IcelkError
+    w, h = 800, 600
+    frames, _ = synth.sequence(w, h, 4, seed=41, max_step_px=2.0)
+    det = (600, 0.007, 8, False, 10)
+    c = Context(w, h, n_slots=4, max_pts=4096)
+    for i, f in enumerate(frames):
+        c.upload_gray(i, f)
+    want = [c.good_features(i, *det) for i in range(4)]
+    lk = ((21, 21), 3, (3, 30, 0.01), 1e-4, 1.0)
+    for prepared in (False, True):
+        if prepared:
+            c.seg_detect_prepare(0, False, 10)
+            c.seg_detect_prepare(1, False, 10)       # a second buffer: the first stays valid
+        c.seg_detect_begin(0, *det)
+        c.seg_detect_begin(1, *det)
+        with pytest.raises(IcelkError, match="-5"):
+            c.seg_detect_begin(2, *det)
+        with pytest.raises(IcelkError, match="-5"):
+            c.good_features(2, *det)
+        c.seg_detect_prepare(2, False, 10)           # the third candidate buffer is free for this
+        n0 = c.seg_detect_stage(det[0])
+        c.seg_switch()
+        t0, _ = c.seg_read()
+        c.seg_detect_begin(2, *det)                  # a set is free again; adopts what was prepared
+        n1 = c.seg_detect_finish(det[0])             # the oldest in flight: frame 1
+        t1, _ = c.seg_read()
+        n2 = c.seg_detect_finish(det[0])
+        t2, _ = c.seg_read()
+        for n, t, ref in ((n0, t0, want[0]), (n1, t1, want[1]), (n2, t2, want[2])):
+            assert n == len(ref) > 300 and np.array_equal(t[:, 0, :], ref.reshape(-1, 2))
+        assert np.array_equal(c.good_features(3, *det), want[3])     # nothing in flight: the one-call form works again
+    c.close()
 
 
 def test_launch_order_is_invisible(synth, monkeypatch):
