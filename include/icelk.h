@@ -174,18 +174,19 @@ int icelk_seg_detect(icelk_t* h, int slot, int use_mask, int max_corners, double
 int icelk_seg_detect_begin(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level,
                            double min_distance, int block_size);
 int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n);
-/* _finish in two halves, for loops that know their frames two steps ahead: _stage waits for the detection in flight
- * and builds the new segment in the handle's spare set of segment buffers while the current segment is still being
- * tracked; icelk_seg_switch (no GPU work, no wait) makes the staged segment the current one.  With the detection of
- * frame c begun at step c-2 and staged at step c-1, the one host round trip of a detection is off the critical path:
- * the tracker launch of frame c+1 finds its segment ready.  _finish == _stage followed by _switch. */
+/* _finish in two halves, for loops that know their frames some steps ahead: _stage waits for the OLDEST detection in
+ * flight and builds the new segment in the handle's next set of segment buffers (four rotate) while the current segment
+ * is still being tracked; icelk_seg_switch (no GPU work, no wait) makes the staged segment the current one.  One
+ * segment can be staged at a time.  With the detection of frame c begun at step c-4 and staged at step c-2 (behind the
+ * _switch of that step), the one host round trip of a detection is off the critical path: the tracker launch of
+ * frame c finds its segment ready.  _finish == _stage followed by _switch. */
 int icelk_seg_detect_stage(icelk_t* h, int max_corners, int* out_n);
 int icelk_seg_switch(icelk_t* h);
 /* Optional, ahead of _begin: produce the corner candidates (min-eigenvalue map + non-max test, the part of
- * s1:437 that depends on nothing but the frame and blockSize) of a frame that is already in `slot`, on a third
- * stream and into a spare buffer, while an earlier detection is still in its min-distance stage.  A later
- * _begin for the same slot/frame/blockSize/mask adopts the result; otherwise it is dropped.  Results are
- * identical either way. */
+ * s1:437 that depends on nothing but the frame and blockSize) of a frame that is already in `slot`, on a stream of
+ * its own and into a spare buffer (three exist: two detections in flight + one prepared), while earlier detections are
+ * still in their min-distance stage.  A later _begin for the same slot/frame/blockSize/mask adopts the result;
+ * otherwise it is dropped.  Results are identical either way. */
 int icelk_seg_detect_prepare(icelk_t* h, int slot, int use_mask, int block_size);
 int icelk_seg_track(icelk_t* h, int slot_prev, int slot_next, int win_w, int win_h, int max_level,
                     int crit_type, int max_count, double epsilon, double min_eig_threshold,
