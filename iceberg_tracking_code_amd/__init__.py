@@ -10,8 +10,8 @@ from .api import (COLOR_BGR2GRAY, COLOR_RGB2GRAY, calcOpticalFlowPyrLK, cvtColor
                   goodFeaturesToTrack, release, set_device, set_gray_variant)
 from .context import (Context, DEFAULT_CRITERIA, GRAY_CV3, GRAY_CV4, OPTFLOW_LK_GET_MIN_EIGENVALS,  # noqa: F401
                       OPTFLOW_USE_INITIAL_FLOW, TERM_CRITERIA_COUNT, TERM_CRITERIA_EPS, TERM_CRITERIA_MAX_ITER)
-from .tracker import (LucasKanade, REF_FB_THRESHOLD, REF_FEATURE_PARAMS, REF_LK_PARAMS, SegmentTracker,  # noqa: F401
-                      npz_name, run_reference_loop, save_tracks, segment_time_ok)
+from .tracker import (REF_FB_THRESHOLD, REF_FEATURE_PARAMS, REF_LK_PARAMS, SegmentTracker,  # noqa: F401
+                      npz_name, save_tracks, segment_time_ok)
 from .utm import CameraModel, REF_UTM_FILTER, cam_to_utm, project_segment, project_tracks, utm_name  # noqa: F401
 from .sequence import track_image_sequence  # noqa: F401
 from .gridding import bin_velocities, create_grid_across_fjord, points_in_polygon  # noqa: F401

@@ -347,6 +347,12 @@ static int begin_frame(Ctx* c, int slot, int w, int h)
     // a detector launch on another stream may still read the frame this slot holds (compute-stream ingest paths
     // write level 0 right after this call; the copy-stream path waits for the same event itself)
     if (int rcw = wait_event(c, c->stream, s.det_used)) return rcw;
+    if (int rcw = wait_event(c, c->stream, s.eig_used)) return rcw;
+    // ... and a pyramid build enqueued ahead (icelk_build_pyramid_ahead) may still be writing levels >= 1 of the frame
+    // this slot held: the ingest paths below clear `pending`, so the dependency is taken here
+    if (s.pending) {
+        if (int rcw = wait_event(c, c->stream, s.ready)) return rcw;
+    }
     s.w = w;
     s.h = h;
     layout_levels(s, w, h);
@@ -582,6 +588,7 @@ static void destroy_ctx(Ctx* c)
         if (s.frame_ev) hipEventDestroy(s.frame_ev);
         if (s.used_own) hipEventDestroy(s.used_own);
         if (s.det_used) hipEventDestroy(s.det_used);
+        if (s.eig_used) hipEventDestroy(s.eig_used);
     }
     if (c->det_stream) hipStreamSynchronize(c->det_stream);
     if (c->eig_stream) hipStreamSynchronize(c->eig_stream);
@@ -803,7 +810,7 @@ static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
     rc = check_launch(c, "corner candidates (prepared)");
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(e.done, es));
-    HIPCHK(c, hipEventRecord(s.det_used, es));
+    HIPCHK(c, hipEventRecord(s.eig_used, es));
     e.nblk = T.src_nblk;
     e.region = T.src_region;
     e.valid = true;
@@ -1291,7 +1298,8 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         if (hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.frame_ev, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.used_own, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.det_used, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&s.det_used, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.eig_used, hipEventDisableTiming) != hipSuccess) {
             c->err = "hipEventCreate failed";
             return fail(ICELK_EHIP);
         }
@@ -1490,6 +1498,7 @@ int icelk_upload_gray_async(icelk_t* h, int slot, const uint8_t* pinned_host, in
     if (int rcw = wait_event(c, cs, s.used)) return rcw;
     if (s.pending) if (int rcw = wait_event(c, cs, s.ready)) return rcw;   // an upload or a pyramid built ahead still in flight
     if (int rcw = wait_event(c, cs, s.det_used)) return rcw;
+    if (int rcw = wait_event(c, cs, s.eig_used)) return rcw;
     HIPCHK(c, hipMemcpy2DAsync(s.lv[0].ptr, s.lv[0].pitch, pinned_host, stride, w, h_, hipMemcpyHostToDevice, cs));
     HIPCHK(c, hipEventRecord(s.ready, cs));
     HIPCHK(c, hipEventRecord(s.frame_ev, cs));
@@ -2011,6 +2020,28 @@ int icelk_seg_switch(icelk_t* h)
 {
     if (!h) return ICELK_EARG;
     return seg_switch(C(h));
+}
+
+int icelk_seg_detect_cancel(icelk_t* h)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    // whatever was enqueued for the abandoned detections runs to its end: nothing is left reading a slot or a mask
+    HIPCHK(c, hipStreamSynchronize(c->eig_stream));
+    HIPCHK(c, hipStreamSynchronize(c->det_stream));
+    HIPCHK(c, hipStreamSynchronize(c->tail_stream));
+    det_save(c);
+    for (auto& S : c->dset)
+        if (S.job.active) {
+            S.job.active = false;
+            S.counters_clean = false;   // its counters were never reset by a tail: the next detection of the set resets them
+        }
+    c->job = c->dset[c->dset_cur].job;
+    c->counters_clean = c->dset[c->dset_cur].counters_clean;
+    for (auto& e : c->eo) e.valid = false;   // prepared candidates are dropped
+    c->seg_staged = false;                   // a staged segment is forgotten (its set is simply staged into again)
+    return ICELK_OK;
 }
 
 int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n)

@@ -66,6 +66,7 @@ struct Slot {
     // `used` refers to the event that covers the latest such launch: the slot's own (`used_own`) or one shared by
     // everything a tracker launch touched (Ctx::launch_ev), so that a launch costs one event record, not one per slot
     hipEvent_t used = nullptr, used_own = nullptr, det_used = nullptr;
+    hipEvent_t eig_used = nullptr;   // the corner kernel of icelk_seg_detect_prepare (candidates stream) reads level 0
     unsigned long long gen = 0;   // bumped whenever a new frame enters the slot
 };
 

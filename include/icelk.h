@@ -174,6 +174,11 @@ int icelk_seg_detect(icelk_t* h, int slot, int use_mask, int max_corners, double
 int icelk_seg_detect_begin(icelk_t* h, int slot, int use_mask, int max_corners, double quality_level,
                            double min_distance, int block_size);
 int icelk_seg_detect_finish(icelk_t* h, int max_corners, int* out_n);
+/* Abandon everything that was started ahead and never used: detections begun but not finished (up to two), prepared
+ * candidates, a staged segment that was never switched to.  Waits for their kernels, then forgets them; the current
+ * segment and every slot stay as they are.  For a loop that announced frames ahead (look-ahead) and ends, or jumps,
+ * before they arrive: afterwards the one-call forms (icelk_good_features, icelk_seg_detect) work again. */
+int icelk_seg_detect_cancel(icelk_t* h);
 /* _finish in two halves, for loops that know their frames some steps ahead: _stage waits for the OLDEST detection in
  * flight and builds the new segment in the handle's next set of segment buffers (four rotate) while the current segment
  * is still being tracked; icelk_seg_switch (no GPU work, no wait) makes the staged segment the current one.  One

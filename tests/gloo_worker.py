@@ -9,8 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle  # noqa: E402
-from iceberg_tracking_code_amd import run_reference_loop, sharding, synth  # noqa: E402
-from test_host_logic import OracleCv  # noqa: E402
+from iceberg_tracking_code_amd import sharding, synth  # noqa: E402
+from reference_loops import OracleCv, run_reference_loop  # noqa: E402
 
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()

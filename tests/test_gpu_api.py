@@ -51,16 +51,17 @@ def test_reference_loops_through_the_gpu_module(orc, synth):
     frames, _ = synth.sequence(320, 240, 5, seed=3, max_step_px=2.0)
     fp = dict(maxCorners=150, qualityLevel=0.007, minDistance=10, blockSize=10)
     lk = dict(winSize=(35, 35), maxLevel=4, criteria=(3, 25, 0.03))
-    got = cv2.run_reference_loop(frames, 2, fp, lk, cv=cv2.api)
-    ref = cv2.run_reference_loop(frames, 2, fp, lk, cv=OracleCv(orc))
+    from reference_loops import LucasKanade, run_reference_loop
+    got = run_reference_loop(frames, 2, fp, lk, cv=cv2.api)
+    ref = run_reference_loop(frames, 2, fp, lk, cv=OracleCv(orc))
     assert len(got) == len(ref) == 2
     for (gf, gt, gq), (rf, rt, rq) in zip(got, ref):
         assert gf == rf and np.array_equal(np.float32(gt), np.float32(rt)) and np.array_equal(np.float32(gq), np.float32(rq))
     # BASELINE.json configs[0]: two 640x480 frames, 200 corners, through the s0_1-shaped class
     f2, _ = synth.sequence(640, 480, 2, seed=1234)
     fp200 = dict(maxCorners=200, qualityLevel=0.007, minDistance=10, blockSize=10)
-    a = cv2.LucasKanade(f2, 3, 120, cv=cv2.api, feature_params=fp200)
-    b = cv2.LucasKanade(f2, 3, 120, cv=OracleCv(orc), feature_params=fp200)
+    a = LucasKanade(f2, 3, 120, cv=cv2.api, feature_params=fp200)
+    b = LucasKanade(f2, 3, 120, cv=OracleCv(orc), feature_params=fp200)
     ta, tb = a.run(), b.run()
     assert a.track_counts == b.track_counts == [0] and len(ta) == len(tb) > 150
     assert np.array_equal(np.float32(ta), np.float32(tb))

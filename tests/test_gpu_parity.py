@@ -328,7 +328,8 @@ class _OracleCv:
 @pytest.mark.parametrize("track_len", [1, 2, 3])
 def test_segment_tracker_equals_reference_loop(orc, synth, track_len):
     """Device-resident loop (SegmentTracker) vs the list-of-lists loop of s1:307-450 run on the oracle."""
-    from iceberg_tracking_code_amd import SegmentTracker, run_reference_loop
+    from iceberg_tracking_code_amd import SegmentTracker
+    from reference_loops import run_reference_loop
     w, h, nfr = 400, 300, 8
     frames, _ = synth.sequence(w, h, nfr, seed=77, max_step_px=2.5)
     mask = np.zeros((h, w), np.uint8)

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 def test_folder_of_jpegs_equals_reference_loop_on_oracle(orc, synth, tmp_path):
     from PIL import Image
-    from iceberg_tracking_code_amd import run_reference_loop, track_image_sequence
+    from iceberg_tracking_code_amd import track_image_sequence
+    from reference_loops import run_reference_loop
     w, h, n, T, dts = 720, 540, 9, 2, 60
     grays, _ = synth.sequence(w, h, n, seed=31, max_step_px=2.0)
     src, dst = tmp_path / "photos", tmp_path / "tracks"

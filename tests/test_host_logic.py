@@ -48,7 +48,7 @@ def test_segment_time_rule():
 
 @pytest.mark.parametrize("track_len", [1, 2, 3])
 def test_reference_loop_bookkeeping(orc, synth, track_len):
-    from iceberg_tracking_code_amd import run_reference_loop
+    from reference_loops import run_reference_loop
     frames, sh = synth.sequence(240, 180, 7, seed=5, max_step_px=2.0)
     fp = dict(maxCorners=120, qualityLevel=0.01, minDistance=8, blockSize=5)
     lk = dict(winSize=(21, 21), maxLevel=2, criteria=(3, 30, 0.01))
@@ -69,7 +69,7 @@ def test_reference_loop_bookkeeping(orc, synth, track_len):
 
 def test_demo_class_counts(orc, synth):
     """s0_1-shaped LucasKanade: BASELINE.json configs[0] plumbing (2 frames 640x480, 200 corners)."""
-    from iceberg_tracking_code_amd import LucasKanade
+    from reference_loops import LucasKanade
     frames, _ = synth.sequence(640, 480, 2, seed=1234)
     lk = LucasKanade(frames, detect_interval=3, time_spacing=120, cv=OracleCv(orc),
                      feature_params=dict(maxCorners=200, qualityLevel=0.007, minDistance=10, blockSize=10))
