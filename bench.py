@@ -288,18 +288,24 @@ def main():
     if cname == "c3":
         K = 64   # BASELINE.json configs[2]: 64 consecutive pairs
     linear = cname in ("c3", "c4")            # a sequence of distinct frames instead of a ping-pong ring
+    if linear and K % TRACK_LEN:
+        raise SystemExit("--steps must be a multiple of track_len (%d) for %s: a rank's block of the sequence starts and ends "
+                         "at a detection frame (sharding.frame_block)" % (TRACK_LEN, cname))
     ring = (W + K + 1) if linear else max(2, min(args.ring, K + W + 1))
     max_pts = max(cfg["max_corners"], 1 << 14) if cfg["max_corners"] > 0 else 1 << 18
     seed = 1234
     # frame g of the GLOBAL sequence (g = 0 is the first timed frame of rank 0; the W warm-up frames precede a rank's
     # block); ring configs use frames 0..ring-1 of a per-rank sequence
     if linear:
-        base = rank * K - W
+        # the rank's frames of the one global sequence: its block of segments plus the closing frame (sharding.frame_block)
+        f0, f1 = sharding.frame_block(world * K + 1, TRACK_LEN, rank, world)
+        assert f1 - f0 == K + 1, (f0, f1, K)
         sh_all, af_all = motion_tables(world * K + 1 + W, seed, args.motion)
-        sh, af = sh_all[base + W:base + W + ring], af_all[base + W:base + W + ring]
+        sh, af = sh_all[f0:f0 + ring], af_all[f0:f0 + ring]
     else:
         sh, af = motion_tables(ring, seed + rank, args.motion)
     ctx = Context(w, h, n_slots=ring, max_pts=max_pts, device=local_rank)
+    probe_info = ctx.stream_probe_info()
     for i in range(ring):
         ctx.synth_frame(i, w, h, int(sh[i, 0]), int(sh[i, 1]), seed if linear else seed + rank, affine=af[i])
     ctx.sync()
@@ -322,7 +328,10 @@ def main():
             tracker.push_slot(order[i], False, *[order[i + k] if i + k < n else None for k in range(1, 7)])
 
     # ---- the timed region -------------------------------------------------------------------------------------------------
-    order = list(range(ring)) if linear else ping_pong(ring, K + W)
+    # ring configs: the visiting order runs on beyond the timed steps, so that the last timed steps look ahead (corner
+    # candidates, min-distance stages, pyramids and joint launches for the frames that follow) exactly as the warm-up looked
+    # ahead for the first timed steps -- the timed region is a window of the steady state: K pairs go out inside it
+    order = list(range(ring)) if linear else ping_pong(ring, K + W + SegmentTracker.MAX_AHEAD)
     archive = None
     if linear:
         # warm-up on the W frames before the rank's block with a tracker of its own that starts nothing ahead of time:
@@ -367,10 +376,16 @@ def main():
     barrier()
     t1 = time.perf_counter()
     ctx.prof_enable(False)
-    n_live, tracked1 = tracker.live()
     prof = ctx.prof_table()
+    consumed = tracker.abort()      # what was started ahead for frames beyond the timed steps is abandoned (it has run)
+    n_live, tracked1 = tracker.live()
     elapsed = t1 - t0
     tracked = tracked1 - tracked0
+    # frame pairs whose tracker launch lies inside the timed region (a joint launch carries two)
+    pairs_launched = None
+    if not args.no_kernel_timing:
+        pairs_launched = (prof.get("lk_fb", {}).get("launches", 0) + 2 * prof.get("lk_fb_pair", {}).get("launches", 0))
+    pairs_timed = K if pairs_launched is None else pairs_launched
 
     # ---- the same kernels once more, each ALONE on the device (outside the timed region): inside the pipeline their
     # HIP-event durations include waiting for wave slots beside the tracker launch ------------------------------------------
@@ -509,12 +524,14 @@ def main():
     exit_code = 0
     if rank == 0:
         top = top_level_of(w, h, cfg["win"], cfg["max_level"])
-        pairs_per_s = world * K / elapsed
+        # every rank runs the same schedule: world x the pairs rank 0 launched inside its timed region
+        pairs_per_s = world * pairs_timed / elapsed
         feats_per_s = sum(tracked_all) / elapsed
         out = {
             "metric": "frame_pairs_per_sec", "value": pairs_per_s, "unit": "frame-pairs/s",
             "tracked_features_per_sec": feats_per_s,
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / max(pairs_timed, 1),
+            "pairs_launched_in_timed_region": pairs_launched, "pairs_expected": K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32/f32",
             "data": "synthetic",
             "config": {"workload": cfg["name"], "width": w, "height": h, "max_corners": cfg["max_corners"],
@@ -526,6 +543,8 @@ def main():
                        "sharding": "one sequence of %d frames, segment blocks per rank (sharding.frame_block), no data-path "
                                    "collective" % (world * K + 1) if linear and world > 1 else "single process",
                        "count_gather": gather["backend"] if gather else None},
+            # which hardware queues the handle's side streams landed on: throughput depends on it, results do not
+            "stream_probe": probe_info,
         }
         if gather:
             out["gather"] = gather
@@ -544,13 +563,18 @@ def main():
             lkp = {"launches": nl, "total_ms": tot_ms, "avg_us": tot_ms * 1e3 / nl,
                    "pairs_per_launch": (sum(k["launches"] for k in lk_kinds) + (prof.get("lk_fb_pair") or {"launches": 0})["launches"]) / nl}
         if lkp:
-            n_avg = tracked / max(lkp["launches"], 1)
-            alg = 2.0 * lk_algorithmic_bytes(w, h, cfg["win"], top, n_avg)   # forward + backward
+            # algorithmic bytes per forward+backward PAIR (per-level cap = 2 frames of that pair) x the pairs
+            # one launch carries
+            n_pair = tracked / max(pairs_timed, 1)
+            alg_pair = 2.0 * lk_algorithmic_bytes(w, h, cfg["win"], top, n_pair)
+            alg = alg_pair * lkp["pairs_per_launch"]
+            n_avg = n_pair * lkp["pairs_per_launch"]
             ach = alg / (lkp["avg_us"] * 1e-6) / 1e9
             out["roofline"] = {"kernel": "k_lk_fast<fb> (fused forward+backward pyramidal LK, all levels)",
                                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                               "algorithmic_bytes_per_launch": alg, "avg_launch_us": lkp["avg_us"],
+                               "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_pair": alg_pair,
+                               "avg_launch_us": lkp["avg_us"],
                                "features_per_launch": n_avg, "frame_pairs_per_launch": lkp["pairs_per_launch"],
                                "note": "LK is VALU-issue-bound (SURVEY.md 8d); HBM fraction reported for completeness, the "
                                        "issue fraction is in valu_issue"}

@@ -82,6 +82,7 @@ SIGNATURES = {
     "icelk_prof_enable": (C.c_int, [handle_p, C.c_int]),
     "icelk_prof_reset": (C.c_int, [handle_p]),
     "icelk_prof_iterations": (C.c_int, [handle_p, C.POINTER(C.c_uint32), C.c_int, i32p]),
+    "icelk_stream_probe_info": (C.c_int, [handle_p, i32p, f64p, f64p]),
     "icelk_prof_count": (C.c_int, []),
     "icelk_prof_name": (C.c_char_p, [C.c_int]),
     "icelk_prof_get": (C.c_int, [handle_p, C.c_int, i32p, f64p]),

@@ -271,6 +271,10 @@ class Context:
         self._ck(self._lib.icelk_seg_detect_stage(self._h, int(maxCorners), C.byref(n)))
         return n.value
 
+    def seg_detect_cancel(self):
+        """Abandon detections begun / prepared / staged ahead and never used (icelk_seg_detect_cancel)."""
+        self._ck(self._lib.icelk_seg_detect_cancel(self._h))
+
     def seg_switch(self):
         self._ck(self._lib.icelk_seg_switch(self._h))
 
@@ -344,6 +348,14 @@ class Context:
         buf = buf[:n.value]
         buf = buf[buf != 0xffffffff]
         return (buf & 0xffff).astype(np.int64), (buf >> 16).astype(np.int64)
+
+    def stream_probe_info(self):
+        """Which hardware queues the side streams of this handle landed on (icelk_stream_probe_info)."""
+        picks = (C.c_int * 4)()
+        q, lim = C.c_double(0), C.c_double(0)
+        self._ck(self._lib.icelk_stream_probe_info(self._h, picks, C.byref(q), C.byref(lim)))
+        return dict(detection=picks[0], candidates=picks[1], pyramid=picks[2], tail=picks[3], quickest=q.value,
+                    limit=lim.value, probed=picks[0] >= 0)
 
     def prof_table(self):
         out = {}

@@ -42,7 +42,8 @@ struct Ctx {
     // pyramids built ahead of their step: not on the copy stream, where a 12 MB upload of a LATER frame would stand
     // between a pyramid and the tracker launch that waits for it
     hipStream_t pyr_stream = nullptr;
-    int side_pick[3] = {-1, -1, -1};   // which of the probed candidate streams became detection / candidates / pyramid
+    int side_pick[4] = {-1, -1, -1, -1};   // which of the probed candidate streams became detection / candidates / pyramid / tail
+    double probe_limit = 0, probe_quickest = 0;
     // Detection (corner candidates, min-distance, sort) runs on its own stream: it only needs the frame,
     // not the tracker's results, so it overlaps the LK launch of the same frame (s1:323-326 vs s1:437).
     hipStream_t det_stream = nullptr;
@@ -546,6 +547,9 @@ static hipError_t create_side_streams(Ctx* c)
         c->side_pick[0] = d;
         c->side_pick[1] = e;
         c->side_pick[2] = q;
+        c->side_pick[3] = t;
+        c->probe_limit = limit;
+        c->probe_quickest = quickest;
         if (getenv("ICELK_STREAM_PROBE_LOG"))
             fprintf(stderr, "icelk probe: detection = candidate %d, candidates stream = %d, pyramid = %d (limit %.2f)\n", d, e, q, limit);
         for (int i = 0; i < NC; i++)
@@ -2436,6 +2440,17 @@ int icelk_prof_iterations(icelk_t* h, uint32_t* host_out, int cap, int* out_n)
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipMemcpy(host_out, c->d_iters, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
     }
+    return ICELK_OK;
+}
+
+int icelk_stream_probe_info(icelk_t* h, int* picks, double* quickest, double* limit)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    if (picks)
+        for (int k = 0; k < 4; k++) picks[k] = c->side_pick[k];
+    if (quickest) *quickest = c->probe_quickest;
+    if (limit) *limit = c->probe_limit;
     return ICELK_OK;
 }
 

@@ -57,14 +57,18 @@ def gather_counts(local_counts, dist=None, device=None, group=None):
     return np.concatenate([p[:k].cpu().numpy() for p, k in zip(parts, sizes)]) if sum(sizes) else np.zeros(0, np.int64)
 
 
-def gather_tables(tracks, counts, dist=None, group=None):
-    """All ranks' per-segment track tables (the `tracks` arrays of s1:394-395), in rank order.
+def gather_tables(tracks, counts, dist=None, group=None, root=0):
+    """The per-segment track tables (the `tracks` arrays of s1:394-395) of all ranks, in rank order, on rank `root`.
 
     tracks: torch tensor (S, R, V, 2) float32 -- S segments of this rank, each padded to R rows, the first counts[s]
-    rows valid; counts: torch tensor (S,) int32/int64 on the same device.  Every rank passes the same R and V; S may
-    differ by one (segment_block), so blocks are padded to the largest S.  Two all_gathers (counts, then tables): with
-    backend "nccl" that is RCCL over xGMI, and the only exchange of a sharded run.  Returns a list with one
-    (first_rows, n) numpy pair per segment of the whole sequence: [(tracks[:n], n), ...].
+    rows valid; counts: torch tensor (S,) int32/int64 on the same device.  Every rank passes the same V; S may differ
+    by one (segment_block).  One all_gather of the per-segment counts (a few hundred bytes: every rank learns how many
+    rows the longest segment of the run has), then ONE gather to `root` of tables cut to that many rows -- not the R the
+    buffers were sized for, and not to every rank: at BASELINE.json configs[3]'s length (1 350 segments of 10 000 x 3 x 2
+    floats per rank) an all_gather of the padded tables would put 8 x 324 MB on every GPU and copy all of it to every
+    host.  With backend "nccl" both are RCCL over xGMI, and the only exchange of a sharded run.
+    Returns on `root` a list with one (first_rows, n) numpy pair per segment of the whole sequence
+    [(tracks[:n], n), ...]; on the other ranks None.
     """
     import torch
     S = int(tracks.shape[0])
@@ -74,6 +78,7 @@ def gather_tables(tracks, counts, dist=None, group=None):
         t = tracks.cpu().numpy()
         return [(t[s, :c[s]].copy(), int(c[s])) for s in range(S)]
     dev = tracks.device
+    rank = dist.get_rank()
     n_seg = torch.tensor([S], dtype=torch.int64, device=dev)
     all_seg = [torch.zeros_like(n_seg) for _ in range(world)]
     dist.all_gather(all_seg, n_seg, group=group)
@@ -81,16 +86,21 @@ def gather_tables(tracks, counts, dist=None, group=None):
     pad = max(max(all_seg), 1)
     cpad = torch.zeros(pad, dtype=torch.int64, device=dev)
     cpad[:S] = counts.to(torch.int64)
-    tpad = torch.zeros((pad,) + tuple(tracks.shape[1:]), dtype=tracks.dtype, device=dev)
-    tpad[:S] = tracks
     call = [torch.zeros_like(cpad) for _ in range(world)]
-    tall = [torch.zeros_like(tpad) for _ in range(world)]
     dist.all_gather(call, cpad, group=group)
-    dist.all_gather(tall, tpad, group=group)
+    call = [c.cpu().numpy() for c in call]
+    rows = max(int(max(int(c.max()) for c in call)), 1)       # the longest segment of the whole run
+    if rows > int(tracks.shape[1]):
+        raise ValueError("a segment count exceeds the rows of the table")
+    tpad = torch.zeros((pad, rows) + tuple(tracks.shape[2:]), dtype=tracks.dtype, device=dev)
+    tpad[:S] = tracks[:, :rows]
+    tall = [torch.zeros_like(tpad) for _ in range(world)] if rank == root else None
+    dist.gather(tpad, tall, dst=root, group=group)
+    if rank != root:
+        return None
     out = []
     for r in range(world):
-        c = call[r].cpu().numpy()
         t = tall[r].cpu().numpy()
         for s in range(all_seg[r]):
-            out.append((t[s, :c[s]].copy(), int(c[s])))
+            out.append((t[s, :call[r][s]].copy(), int(call[r][s])))
     return out

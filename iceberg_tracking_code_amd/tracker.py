@@ -86,6 +86,7 @@ class SegmentTracker:
         # closed=True: the switch has happened (its last pair went out in a joint launch, see `_step`)
         self.on_close = None
         self._advanced = False    # the pair (cur, next) has gone out already, with the joint launch of this step
+        self._advanced_slot = None   # ... and `next` was announced to sit in this slot
         self._det_queue = []      # detections in flight, oldest first: (frame counter, step at which it was begun)
         self._begun_upto = -1     # latest frame whose detection has been begun
         self._prep_upto = -1      # latest frame whose corner candidates have been prepared ahead
@@ -207,14 +208,19 @@ class SegmentTracker:
             self._begun_upto = c
         joint = False
         if self._advanced:
-            self._advanced = False            # the pair (prev, slot) went out with the launch of the previous step
+            # the pair (prev, slot) went out with the launch of the previous step -- on the strength of the slot that was
+            # announced for this frame then
+            if slot != self._advanced_slot:
+                raise RuntimeError("frame pushed in slot %d, but slot %d was announced for it one step ago (its pair has "
+                                   "been launched already)" % (slot, self._advanced_slot))
+            self._advanced = False
         elif self.active:
             joint = detect and self.pair_launch and not wait and staged_now and next_slot is not None and c > 0
             if joint:
                 self.ctx.seg_track_defer(prev, slot, *lk_tail)
                 self.ctx.seg_switch()
                 self.ctx.seg_track(slot, next_slot, *lk_tail, wait=False)
-                self._advanced = True
+                self._advanced, self._advanced_slot = True, next_slot
                 if self.on_close is not None:
                     self.on_close(self.seg_first, True)
                 self.n_detected = self._staged_n
@@ -281,6 +287,24 @@ class SegmentTracker:
 
     def live(self):
         return self.ctx.seg_live()
+
+    def abort(self):
+        """End (or interrupt) a sequence whose announced frames will not all be pushed: a pair held back inside the library
+        goes out, detections begun / prepared / staged ahead for frames that never came are abandoned
+        (icelk_seg_detect_cancel).  The current segment stays readable; the handle's one-call detector forms work again,
+        and pushing may continue -- the next detection frame then starts its detection when it arrives.  Returns the
+        number of frames consumed so far."""
+        self.ctx.seg_flush()
+        self.ctx.seg_detect_cancel()
+        if self._advanced:
+            # a joint launch has already tracked the pair into the frame announced for the next step (it sat in its slot):
+            # that frame counts as consumed -- it is never a detection frame (track_len >= 2 wherever pairs are joined)
+            self.cur, self.counter, self._advanced = self._advanced_slot, self.counter + 1, False
+        self._det_queue = []
+        self._staged, self._staged_for, self._staged_n = False, None, 0
+        self._begun_upto = self._prep_upto = self.counter - 1
+        self._pyr_ahead = set()
+        return self.counter
 
     def close(self):
         self.ctx.close()

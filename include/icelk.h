@@ -286,6 +286,12 @@ int icelk_prof_reset(icelk_t* h);
  * bits, backward pass in the high 16 (0xffffffff = a track that was already dead); *out_n = features of that call.
  * The iterations-per-feature histogram of bench.py comes from here. */
 int icelk_prof_iterations(icelk_t* h, uint32_t* host_out, int cap, int* out_n);
+/* Outcome of the hardware-queue probe icelk_create ran for this handle: picks[0..3] = which of the eight
+ * candidate streams became the detection / candidates / pyramid / tail stream (-1: ICELK_NO_STREAM_PROBE, creation
+ * order); *quickest = the smallest fraction of the filler's duration after which a one-wave kernel on a candidate stream
+ * came back beside a busy compute stream, *limit = the fraction above which a stream counted as held up.  Throughput
+ * depends on these picks, results do not: bench.py records them with every line. */
+int icelk_stream_probe_info(icelk_t* h, int* picks, double* quickest, double* limit);
 int icelk_prof_count(void);
 const char* icelk_prof_name(int kernel_id);
 int icelk_prof_get(icelk_t* h, int kernel_id, int* launches, double* total_ms);

@@ -13,4 +13,5 @@ from .cpu import (  # noqa: F401
     CRIT_COUNT, CRIT_EPS, FLAG_INITIAL_FLOW, FLAG_MIN_EIGENVALS,
     build, lib, set_threads, set_fb_distance, fb_distance, lk_stats, bgr2gray, pyrdown, pyramid_levels, build_pyramid, scharr,
     pyrlk, track_fb, min_eig_map, good_features, project_tracks, polygon_mask, points_in_polygon, grid_bin,
+    VARIANTS, set_variant, get_variant, variants,
 )

@@ -65,6 +65,8 @@ def lib():
                                    C.c_int, C.c_double, C.c_double, C.c_float]
         L.orc_min_eig_map.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
         L.orc_set_fb_distance.argtypes = [C.c_int]
+        L.orc_set_variant.argtypes = [C.c_char_p, C.c_int]
+        L.orc_get_variant.argtypes = [C.c_char_p]
         L.orc_fb_distance.argtypes = [C.c_float] * 4
         L.orc_fb_distance.restype = C.c_float
         L.orc_good_features.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_double,
@@ -211,6 +213,36 @@ def track_fb(img0, img1, p0, winSize=(21, 21), maxLevel=3, criteria=(CRIT_COUNT 
                             _p(dist, _f32p), _p(valid, _u8p), n, winSize[0], winSize[1], maxLevel, t, cnt, eps,
                             minEigThreshold, fb_threshold))
     return dict(p1=p1, p0r=p0r, st_fwd=st_f, st_bwd=st_b, err_fwd=er_f, err_bwd=er_b, dist=dist, valid=valid)
+
+
+VARIANTS = {"lk_sums": (0, 1, 2), "sobel_fma": (0, 1, 2, 3), "eig_fma": (0, 1)}
+
+
+def set_variant(name, value):
+    """Select a named variant of a build-dependent OpenCV semantic (icelk_oracle.c: orc_set_variant); 0 = the default,
+    which is what the HIP kernels compute.  Process-wide: reset it when done (`variants()` does)."""
+    if lib().orc_set_variant(name.encode(), int(value)) != 0:
+        raise ValueError("unknown oracle variant %s=%r" % (name, value))
+
+
+def get_variant(name):
+    return lib().orc_get_variant(name.encode())
+
+
+class variants:
+    """with oracle.variants(lk_sums=1, eig_fma=1): ...   -- the switches go back to their defaults on exit."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            set_variant(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in VARIANTS:
+            set_variant(k, 0)
 
 
 def min_eig_map(img, blockSize=3):

@@ -75,6 +75,86 @@ int orc_set_threads(int n)
 #endif
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Named variants of the build-dependent OpenCV semantics ("a named, unit-tested switch").
+ * The DEFAULT of each is what the HIP kernels compute; the others exist to measure how far a differently built
+ * OpenCV could be from it (tools/oracle_variants.py).  All are from knowledge of upstream
+ * OpenCV's sources -- none can be checked against a cv2 binary here.
+ *
+ *   "lk_sums"   0  A11,A12,A22,b1,b2 accumulated exactly (int64), converted to float once  [default]
+ *               1  OpenCV 3.x x86 SSE2 block of LKTrackerInvoker: the matrix sums in four float lanes over groups of 4
+ *                  pixels of a window row (lane = x mod 4, every product exact in float, one rounding per add), the
+ *                  pixels of a row beyond the last whole group in a scalar float accumulator, at the end
+ *                  acc += ((l0 + l1) + l2) + l3; the residual sums b1,b2 in 2 x 4 lanes over groups of 8 pixels
+ *                  (products converted int32 -> float first: they exceed 2^24), acc += (q0[k] + q1[k]) pairs
+ *               2  OpenCV 4.x universal-intrinsic block (CV_SIMD128): as 1 but the matrix sums walk groups of 8
+ *                  pixels (so a 21-px row leaves 5 pixels to the scalar accumulator instead of 1) and the lanes are
+ *                  folded pairwise, (l0 + l2) + (l1 + l3) (v_reduce_sum)
+ *   "sobel_fma" bit 0: the symmetric column pass of the scaled Sobel kernel fused, fmaf(r0 + r2, k1, r1 * k0)
+ *                  (4.x SymmColumnSmallVec_32f's v_muladd in an FMA3 / AVX2-dispatched build)
+ *               bit 1: the row pass k1*l + k0*c + k1*r with its two additions fused (a RowFilter loop contracted by
+ *                  a compiler that targets FMA)
+ *   "eig_fma"   1  calcMinEigenVal's (a-c)^2 + b^2 as fmaf(b, b, t*t) (4.x v_muladd(v_b, v_b, v_t * v_t))
+ * ---------------------------------------------------------------------------------------- */
+static int g_lk_sums = 0, g_sobel_fma = 0, g_eig_fma = 0;
+int orc_set_variant(const char* name, int value)
+{
+    if (!name) return ORC_EARG;
+    if (!strcmp(name, "lk_sums") && value >= 0 && value <= 2) { g_lk_sums = value; return ORC_OK; }
+    if (!strcmp(name, "sobel_fma") && value >= 0 && value <= 3) { g_sobel_fma = value; return ORC_OK; }
+    if (!strcmp(name, "eig_fma") && (value == 0 || value == 1)) { g_eig_fma = value; return ORC_OK; }
+    return ORC_EARG;
+}
+int orc_get_variant(const char* name)
+{
+    if (!name) return ORC_EARG;
+    if (!strcmp(name, "lk_sums")) return g_lk_sums;
+    if (!strcmp(name, "sobel_fma")) return g_sobel_fma;
+    if (!strcmp(name, "eig_fma")) return g_eig_fma;
+    return ORC_EARG;
+}
+
+/* float-lane accumulators of the x86 SIMD blocks (lk_sums 1 / 2) */
+typedef struct { float q[3][4]; float t[3]; } orc_lanes_a;   /* A11, A12, A22: four lanes + scalar accumulator */
+typedef struct { float q0[4], q1[4]; float t[2]; } orc_lanes_b;
+
+static void lanes_a_row(orc_lanes_a* L, const int16_t* dI, int win_w, int group)
+{
+    int x = 0;
+    for (; x <= win_w - group; x += group)
+        for (int k = 0; k < group; k++) {
+            const float fx = (float)dI[2 * (x + k)], fy = (float)dI[2 * (x + k) + 1];
+            float* a11 = &L->q[0][k & 3]; float* a12 = &L->q[1][k & 3]; float* a22 = &L->q[2][k & 3];
+            *a22 = *a22 + fy * fy;
+            *a12 = *a12 + fx * fy;
+            *a11 = *a11 + fx * fx;
+        }
+    for (; x < win_w; x++) {
+        const int ix = dI[2 * x], iy = dI[2 * x + 1];
+        L->t[0] += (float)(ix * ix);
+        L->t[1] += (float)(ix * iy);
+        L->t[2] += (float)(iy * iy);
+    }
+}
+
+static float lanes_a_fold(const orc_lanes_a* L, int which, int mode)
+{
+    const float* q = L->q[which];
+    float acc = L->t[which];
+    if (mode == 1) acc += ((q[0] + q[1]) + q[2]) + q[3];
+    else acc += (q[0] + q[2]) + (q[1] + q[3]);
+    return acc;
+}
+
+/* one pixel's residual x gradient products into the lane the SIMD block puts them in */
+static void lanes_b_px(orc_lanes_b* L, int k, int diff, int ix, int iy)
+{
+    float* q = ((k >> 1) & 1) ? L->q1 : L->q0;      /* pixels 0,1,4,5 of a group of 8 -> q0; 2,3,6,7 -> q1 */
+    const int lane = (k & 1) * 2;
+    q[lane] = q[lane] + (float)(diff * ix);
+    q[lane + 1] = q[lane + 1] + (float)(diff * iy);
+}
+
 /* BORDER_REFLECT_101:  ... 2 1 | 0 1 2 ... n-2 n-1 | n-2 n-3 ...    */
 static int reflect101(int p, int n)
 {
@@ -400,6 +480,8 @@ int orc_pyrlk(const uint8_t* prev, int prev_stride, const uint8_t* next, int nex
 
                 n_patches++;
                 int64_t iA11 = 0, iA12 = 0, iA22 = 0;
+                orc_lanes_a LA;
+                memset(&LA, 0, sizeof LA);
                 for (int y = 0; y < win_h; y++) {
                     const uint8_t* src = LI->img + (ptrdiff_t)(y + ipy) * stepI + ipx;
                     const int16_t* dsrc = deriv + (ptrdiff_t)(y + ipy) * dstep + (ptrdiff_t)ipx * 2;
@@ -419,10 +501,16 @@ int orc_pyrlk(const uint8_t* prev, int prev_stride, const uint8_t* next, int nex
                         iA12 += (int64_t)ixval * iyval;
                         iA22 += (int64_t)iyval * iyval;
                     }
+                    if (g_lk_sums) lanes_a_row(&LA, dIwin + (size_t)y * win_w * 2, win_w, g_lk_sums == 1 ? 4 : 8);
                 }
                 float A11 = (float)iA11 * FLT_SCALE;
                 float A12 = (float)iA12 * FLT_SCALE;
                 float A22 = (float)iA22 * FLT_SCALE;
+                if (g_lk_sums) {
+                    A11 = lanes_a_fold(&LA, 0, g_lk_sums) * FLT_SCALE;
+                    A12 = lanes_a_fold(&LA, 1, g_lk_sums) * FLT_SCALE;
+                    A22 = lanes_a_fold(&LA, 2, g_lk_sums) * FLT_SCALE;
+                }
                 float D = A11 * A22 - A12 * A12;
                 float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
                                (float)(2 * win_w * win_h);
@@ -444,6 +532,9 @@ int orc_pyrlk(const uint8_t* prev, int prev_stride, const uint8_t* next, int nex
                     a = nx - inx; b = ny - iny;
                     bilinear_weights(a, b, &iw00, &iw01, &iw10, &iw11);
                     int64_t ib1 = 0, ib2 = 0;
+                    orc_lanes_b LB;
+                    memset(&LB, 0, sizeof LB);
+                    const int whole8 = win_w & ~7;     /* pixels of a row the 8-wide SIMD block covers */
                     for (int y = 0; y < win_h; y++) {
                         const uint8_t* Jp = LJ->img + (ptrdiff_t)(y + iny) * stepJ + inx;
                         const int16_t* Ip = Iwin + (size_t)y * win_w;
@@ -453,10 +544,20 @@ int orc_pyrlk(const uint8_t* prev, int prev_stride, const uint8_t* next, int nex
                                                Jp[x + stepJ + 1] * iw11, W_BITS - 5) - Ip[x];
                             ib1 += (int64_t)diff * dIp[0];
                             ib2 += (int64_t)diff * dIp[1];
+                            if (g_lk_sums) {
+                                if (x < whole8) lanes_b_px(&LB, x & 7, diff, dIp[0], dIp[1]);
+                                else { LB.t[0] += (float)(diff * dIp[0]); LB.t[1] += (float)(diff * dIp[1]); }
+                            }
                         }
                     }
                     float b1 = (float)ib1 * FLT_SCALE;
                     float b2 = (float)ib2 * FLT_SCALE;
+                    if (g_lk_sums) {
+                        float sb[4];
+                        for (int k = 0; k < 4; k++) sb[k] = LB.q0[k] + LB.q1[k];
+                        b1 = (LB.t[0] + (sb[0] + sb[2])) * FLT_SCALE;
+                        b2 = (LB.t[1] + (sb[1] + sb[3])) * FLT_SCALE;
+                    }
                     float dx = (A12 * b2 - A22 * b1) * D;
                     float dy = (A12 * b1 - A11 * b2) * D;
                     nx += dx; ny += dy;
@@ -566,8 +667,13 @@ int orc_min_eig_map(const uint8_t* img, int w, int h, int stride, int block_size
             int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
             rdx[(size_t)y * w + x] = (float)s[xp] - (float)s[xm];
             float t = k1 * (float)s[xm];
-            t = t + k0 * (float)s[x];
-            t = t + k1 * (float)s[xp];
+            if (g_sobel_fma & 2) {
+                t = fmaf(k0, (float)s[x], t);
+                t = fmaf(k1, (float)s[xp], t);
+            } else {
+                t = t + k0 * (float)s[x];
+                t = t + k1 * (float)s[xp];
+            }
             rdy[(size_t)y * w + x] = t;
         }
     }
@@ -576,7 +682,11 @@ int orc_min_eig_map(const uint8_t* img, int w, int h, int stride, int block_size
     for (int y = 0; y < h; y++) {
         int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
         for (int x = 0; x < w; x++) {
-            float dx = (rdx[(size_t)ym * w + x] + rdx[(size_t)yp * w + x]) * k1 + rdx[(size_t)y * w + x] * k0;
+            float dx;
+            if (g_sobel_fma & 1)
+                dx = fmaf(rdx[(size_t)ym * w + x] + rdx[(size_t)yp * w + x], k1, rdx[(size_t)y * w + x] * k0);
+            else
+                dx = (rdx[(size_t)ym * w + x] + rdx[(size_t)yp * w + x]) * k1 + rdx[(size_t)y * w + x] * k0;
             float dy = rdy[(size_t)yp * w + x] - rdy[(size_t)ym * w + x];
             float* c = cov + ((size_t)y * w + x) * 3;
             c[0] = dx * dx;
@@ -607,7 +717,8 @@ int orc_min_eig_map(const uint8_t* img, int w, int h, int stride, int block_size
                 s0 += r[0]; s1 += r[1]; s2 += r[2];
             }
             float a = (float)s0 * 0.5f, b = (float)s1, c = (float)s2 * 0.5f;
-            eig[(size_t)y * w + x] = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+            const float t = a - c;
+            eig[(size_t)y * w + x] = (a + c) - sqrtf(g_eig_fma ? fmaf(b, b, t * t) : t * t + b * b);
         }
     }
     free(rdx); free(cov); free(rs);
