@@ -239,6 +239,12 @@ class Context:
             return None
         return out[:n.value].reshape(-1, 1, 2).copy()
 
+    def detect_fast_stats(self, w, h):
+        out = (C.c_longlong * 8)()
+        self._ck(self._lib.icelk_detect_fast_stats(self._h, int(w), int(h), out))
+        return dict(tiles=out[0], listed=out[1], whole_tiles=out[2], ties=out[3], max_listed=out[4], max_overflow_tiles=out[5],
+                    longest_list=out[6], evaluated=out[7])
+
     def detect_stats(self):
         a, b = C.c_int(0), C.c_int(0)
         self._ck(self._lib.icelk_detect_stats(self._h, C.byref(a), C.byref(b)))

@@ -76,6 +76,15 @@ struct Ctx {
         unsigned long long* raw = nullptr;
         int* blk_count = nullptr;
         unsigned* max_key = nullptr;
+        // scratch of the two-pass detector (DetectScratch::acand ...)
+        uint2* acand = nullptr;
+        int* acount = nullptr;
+        uint2* amaxc = nullptr;
+        int* amaxn = nullptr;
+        float* aemax = nullptr;
+        unsigned* fmax_key = nullptr;
+        unsigned* aties = nullptr;
+        double quality = 0;          // candidates below max * quality were never given their exact key (0: none were cut)
         int nblk = 0, region = 0;
         bool valid = false;          // holds the candidates of (slot, gen) for (block_size, use_mask, mask_gen)
         int slot = -1, block_size = 0, use_mask = 0;
@@ -104,6 +113,7 @@ struct Ctx {
     unsigned long long job_seq = 0;
     hipStream_t eig_stream = nullptr;
     unsigned long long mask_gen = 0;
+    double prep_quality = 0;   // qualityLevel of the latest detection begun: what icelk_seg_detect_prepare cuts its candidates at
 
     // segment state
     // Segment state, two sets: while the tracker launch of a detection frame still extends the closing segment in
@@ -620,6 +630,11 @@ static void destroy_ctx(Ctx* c)
         for (void* q : ep)
             if (q) hipFree(q);
     }
+    for (auto& e : c->eo) {
+        void* fp[] = {e.acand, e.acount, e.amaxc, e.amaxn, e.aemax, e.fmax_key, e.aties};
+        for (void* q : fp)
+            if (q) hipFree(q);
+    }
     for (auto& e : c->eo) {   // [0] and [1] are in the list below
         if (&e == &c->eo[2]) {
             if (e.raw) hipFree(e.raw);
@@ -770,6 +785,13 @@ static void activate_eig_out(Ctx* c, int idx)
     c->D.raw = e.raw;
     c->D.blk_count = e.blk_count;
     c->D.max_key = e.max_key;
+    c->D.acand = e.acand;
+    c->D.acount = e.acount;
+    c->D.amaxc = e.amaxc;
+    c->D.amaxn = e.amaxn;
+    c->D.aemax = e.aemax;
+    c->D.fmax_key = e.fmax_key;
+    c->D.aties = e.aties;
     c->D.src_nblk = e.nblk;
     c->D.src_region = e.region;
 }
@@ -807,9 +829,19 @@ static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
     T.raw = e.raw;
     T.blk_count = e.blk_count;
     T.max_key = e.max_key;
+    T.acand = e.acand;
+    T.acount = e.acount;
+    T.amaxc = e.amaxc;
+    T.amaxn = e.amaxn;
+    T.aemax = e.aemax;
+    T.fmax_key = e.fmax_key;
+    T.aties = e.aties;
+    // the quality level is not known yet: the one of the latest detection begun on this handle is taken (0 at first: every
+    // local maximum gets its exact key); detect_begin adopts the result only if its own level is not lower
+    const double prep_quality = c->prep_quality;
     {
         ProfScope p(c, K_EIG, es);
-        launch_candidates(es, T, s.lv[0], block_size, mask, c->mask_pitch, 1.0, false, nullptr);
+        launch_candidates(es, T, s.lv[0], block_size, mask, c->mask_pitch, prep_quality, false, nullptr);
     }
     rc = check_launch(c, "corner candidates (prepared)");
     if (rc) return rc;
@@ -823,6 +855,7 @@ static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
     e.block_size = block_size;
     e.use_mask = use_mask;
     e.mask_gen = c->mask_gen;
+    e.quality = prep_quality;
     return ICELK_OK;
 }
 
@@ -873,7 +906,8 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
     const int spare_idx = eo_free(c, &want);
     Ctx::EigOut& spare = c->eo[spare_idx];
     const bool prepared = spare.valid && spare.slot == slot && spare.gen == s.gen && spare.block_size == block_size &&
-                          spare.use_mask == use_mask && spare.mask_gen == c->mask_gen && !generic;
+                          spare.use_mask == use_mask && spare.mask_gen == c->mask_gen && !generic && spare.quality <= quality;
+    c->prep_quality = quality;
     spare.valid = false;   // adopted below, or overwritten: either way it is not offered again
     if (prepared) {
         if (need_reset) launch_detect_reset(ds, D, (int)ncell, 1);
@@ -1372,6 +1406,12 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
     if ((rc = dmalloc(c, &c->eo[2].max_key, 1)) || (rc = dmalloc(c, &c->eo[2].raw, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &c->eo[2].blk_count, candidate_blocks(max_w, max_h) * 4)))
         return fail(rc);
+    for (auto& e : c->eo)
+        if ((rc = dmalloc(c, &e.acand, fast_cand_entries(max_w, max_h))) || (rc = dmalloc(c, &e.acount, fast_tiles(max_w, max_h))) ||
+            (rc = dmalloc(c, &e.amaxc, fast_max_entries(max_w, max_h))) || (rc = dmalloc(c, &e.amaxn, fast_tiles(max_w, max_h))) ||
+            (rc = dmalloc(c, &e.aemax, fast_tiles(max_w, max_h))) || (rc = dmalloc(c, &e.fmax_key, 8)) ||
+            (rc = dmalloc(c, &e.aties, fast_cand_entries(max_w, max_h) + fast_tiles(max_w, max_h))))
+            return fail(rc);
     if (hipEventCreateWithFlags(&c->eo[2].done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->counts_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->tail_done, hipEventDisableTiming) != hipSuccess) {
@@ -1406,6 +1446,8 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         E.raw = c->eo[1].raw;
         E.blk_count = c->eo[1].blk_count;
         E.max_key = c->eo[1].max_key;
+        E.acand = c->eo[1].acand; E.acount = c->eo[1].acount; E.amaxc = c->eo[1].amaxc; E.amaxn = c->eo[1].amaxn;
+        E.aemax = c->eo[1].aemax; E.fmax_key = c->eo[1].fmax_key; E.aties = c->eo[1].aties;
     }
     if (hipMemset(c->d_tracked, 0, 64 * 8) != hipSuccess) {
         c->err = "hipMemset failed";
@@ -1947,6 +1989,33 @@ int icelk_detect_stats(icelk_t* h, int* n_candidates, int* n_accepted)
     Ctx* c = C(h);
     if (n_candidates) *n_candidates = c->last_candidates;
     if (n_accepted) *n_accepted = c->last_accepted;
+    return ICELK_OK;
+}
+
+int icelk_detect_fast_stats(icelk_t* h, int slot_w, int slot_h, long long* out)
+{
+    if (!h || !out) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    det_save(c);
+    const Ctx::EigOut& e = c->eo[c->eo_active];
+    const size_t nt = fast_tiles(slot_w, slot_h);
+    std::vector<int> cnt(nt), mx(nt);
+    unsigned fk[3] = {0, 0, 0};
+    HIPCHK(c, hipMemcpy(cnt.data(), e.acount, nt * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(mx.data(), e.amaxn, nt * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(fk, e.fmax_key, sizeof fk, hipMemcpyDeviceToHost));
+    long long listed = 0, whole = 0, maxc = 0, maxover = 0, biggest = 0;
+    for (size_t i = 0; i < nt; i++) {
+        if (cnt[i] > 256) whole++;
+        else listed += cnt[i];
+        if (cnt[i] > biggest) biggest = cnt[i];
+        if (mx[i] > 16) maxover++;
+        else maxc += mx[i];
+    }
+    out[0] = (long long)nt; out[1] = listed; out[2] = whole; out[3] = (long long)fk[1]; out[4] = maxc; out[5] = maxover;
+    out[6] = biggest; out[7] = (long long)fk[2];
     return ICELK_OK;
 }
 

@@ -156,6 +156,16 @@ struct DetectScratch {
     unsigned* key_hist;    // histogram of the response keys (top-K pruning); 65536 entries allocated
     unsigned* prune_key;   // 1: candidates with a smaller response key are ignored (0 = none)
     int src_nblk, src_region;   // geometry of the candidate regions of the detection in flight
+    // two-pass detector (k_corners_fast.hip): what its integer pass hands to its exact passes -- per tile the pixels that can
+    // be a local maximum {y << 16 | x, upper bound} and those that can carry the maximum, the tile's largest upper bound,
+    // and the largest lower bound of the whole frame.  These belong to the candidate buffer (Ctx::EigOut), like raw.
+    uint2* acand;
+    int* acount;
+    uint2* amaxc;
+    int* amaxn;
+    float* aemax;
+    unsigned* fmax_key;      // [0] largest lower bound of the frame, [1] entries in aties
+    unsigned* aties;         // pixels (y << 16 | x) whose neighbourhood the exact pass must look at; 0x80000000 | tile: whole tile
 };
 void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig, const uint8_t* mask,
                     int mask_pitch, unsigned* max_key);
@@ -166,6 +176,15 @@ void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, int mode);
 // K6+K7: local maxima into per-workgroup regions of D.raw (stream order, no host sync)
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
                        int mask_pitch, double quality, bool use_generic, float* eig_out_or_null);
+// K6 + K7 in two passes for blockSize 3 / 5 / 7 / 10 (integer bracket of the map, exact arithmetic at the possible maxima
+// only): same regions, counts and max_key as launch_candidates' one-pass kernel.  quality <= 0: no threshold cut.
+bool launch_candidates_fast(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
+                            int mask_pitch, double quality);
+size_t fast_tiles(int w, int h);
+size_t fast_cand_entries(int w, int h);
+size_t fast_max_entries(int w, int h);
+size_t fast_key_capacity(int w, int h);
+size_t fast_regions(int w, int h);
 size_t candidate_capacity(int w, int h);   // keys the region layout needs
 size_t candidate_blocks(int w, int h);
 // minDistance < 1: candidates above the threshold, flat in D.cand / D.cand_count

@@ -838,9 +838,15 @@ size_t candidate_capacity(int w, int h)
 {
     const size_t fused = (size_t)((w + 63) / 64) * ((h + 15) / 16) * (64 * 16);
     const size_t generic = (size_t)((w + 255) / 256) * ((h + NMS_ROWS - 1) / NMS_ROWS) * (256 * NMS_ROWS);
-    return (fused > generic ? fused : generic) + 1024;
+    const size_t fast = fast_key_capacity(w, h);
+    const size_t m = fused > generic ? fused : generic;
+    return (m > fast ? m : fast) + 1024;
 }
-size_t candidate_blocks(int w, int h) { return (size_t)((w + 63) / 64) * ((h + 15) / 16) + 16; }
+size_t candidate_blocks(int w, int h)
+{
+    const size_t a = (size_t)((w + 63) / 64) * ((h + 15) / 16), b = fast_regions(w, h);
+    return (a > b ? a : b) + 16;
+}
 
 // K6 alone, writing the map with the any-blockSize kernel.
 void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig, const uint8_t* mask,
@@ -888,6 +894,12 @@ void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int bl
 {
     unsigned long long* raw = D.raw;
     CandSrc g_src{};
+    // ICELK_TWO_PASS_CORNERS=1: the two-pass form (k_corners_fast.hip: integer bracket of the map + exact arithmetic at the
+    // possible maxima) -- a third statement of the arithmetic, bit-identical, measured and not the default
+    const bool two_pass = getenv("ICELK_TWO_PASS_CORNERS") != nullptr;
+    if (two_pass && !use_generic && fused_block_size(block_size) && !eig_out_or_null &&
+        launch_candidates_fast(s, D, img, block_size, mask, mask_pitch, quality))
+        return;
     if (!use_generic && fused_block_size(block_size)) {
         float k0, k1;
         sobel_scale(block_size, &k0, &k1);

@@ -158,6 +158,11 @@ int icelk_good_features(icelk_t* h, int slot, int use_mask, int max_corners, dou
 /* Work counters of the latest detection on this handle: local maxima above the quality threshold, and
  * corners surviving the minDistance rule (before the maxCorners cut). */
 int icelk_detect_stats(icelk_t* h, int* n_candidates, int* n_accepted);
+/* Work counters of the two-pass candidate stage of the latest detection on a frame_w x frame_h frame (diagnostics; waits
+ * for the device): out[0] tiles, [1] pixels listed as possible local maxima, [2] tiles whose list overflowed, [3] entries
+ * handed to the 3x3 tie pass, [4] pixels listed as possible carriers of the maximum, [5] tiles whose such list overflowed,
+ * [6] longest tile list, [7] listed pixels that got their exact value in the one-pixel pass (certain, above the cut). */
+int icelk_detect_fast_stats(icelk_t* h, int frame_w, int frame_h, long long* out);
 
 /* ---- device-resident segment state: the `tracks` / `trackquality` lists of s1:299-300,335-359 --
  * A segment starts at a detection frame (counter % track_len == 0, s1:362,437-448) and is extended

@@ -409,3 +409,43 @@ def test_fb_distance_is_numpy_hypot(ctx, orc, synth):
     hyp = np.hypot(dd[:, 0], dd[:, 1])
     assert np.array_equal(g["dist"].view(np.uint32), hyp.view(np.uint32))
     assert np.array_equal(g["valid"].astype(bool), hyp < 1)
+
+
+@pytest.mark.parametrize("bs", [3, 5, 7, 10])
+def test_two_pass_corner_detector(orc, synth, bs, monkeypatch):
+    """ICELK_TWO_PASS_CORNERS=1: the integer bracket of the eigenvalue map + OpenCV's float arithmetic at the possible maxima
+    only (k_corners_fast.hip) gives the corner list of the one-pass kernel and of the oracle -- with a mask, on a frame
+    whose tiles hang over every border, on flat regions (exact zeros), plateaus (ties, list overflow) and frames smaller
+    than a window."""
+    from iceberg_tracking_code_amd import Context
+    monkeypatch.setenv("ICELK_TWO_PASS_CORNERS", "1")
+    rng = np.random.RandomState(bs)
+    cases = []
+    img = synth.frame(701, 467, 5, -3, 77)
+    mask = np.zeros_like(img)
+    mask[40:400, 60:650] = 255
+    mask[100:160, 200:300] = 0
+    cases.append((img, None, 0, 0.007, 10))
+    cases.append((img, mask, 300, 0.02, 6))
+    flat = img.copy()
+    flat[150:320, 100:500] = 93                                   # a flat region: eigenvalue exactly zero inside
+    cases.append((flat, None, 0, 0.01, 4))
+    ramp = (np.add.outer(np.arange(200), 2 * np.arange(300)) % 256).astype(np.uint8)   # plateaus of equal response
+    cases.append((ramp, None, 0, 0.05, 0))
+    cases.append((rng.randint(0, 256, (9, 13)).astype(np.uint8), None, 0, 0.01, 1))   # smaller than a tile and a window
+    cases.append((rng.randint(0, 256, (64, 3)).astype(np.uint8), None, 0, 0.01, 1))
+    c = Context(1024, 768, n_slots=1, max_pts=1 << 17)
+    for im, m, maxc, q, md in cases:
+        c.upload_gray(0, im)
+        c.set_mask(m)
+        got = c.good_features(0, maxc, q, md, m is not None, bs)
+        ref = orc.good_features(im, maxc, q, md, m, bs)
+        assert (got is None) == (ref is None), (im.shape, bs)
+        if ref is not None:
+            assert np.array_equal(got, ref), (im.shape, bs, len(got), len(ref))
+    c.set_mask(None)
+    # the one-pass kernel on the same handle (switch read per call)
+    monkeypatch.delenv("ICELK_TWO_PASS_CORNERS")
+    c.upload_gray(0, img)
+    assert np.array_equal(c.good_features(0, 0, 0.007, 10, False, bs), orc.good_features(img, 0, 0.007, 10, None, bs))
+    c.close()
