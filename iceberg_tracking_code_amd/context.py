@@ -277,6 +277,12 @@ class Context:
         self._ck(self._lib.icelk_seg_detect_stage(self._h, int(maxCorners), C.byref(n)))
         return n.value
 
+    def seg_detect_stage_try(self, maxCorners):
+        """icelk_seg_detect_stage_try: the corner count once the oldest detection in flight is through, else None (no wait)."""
+        n, done = C.c_int(0), C.c_int(0)
+        self._ck(self._lib.icelk_seg_detect_stage_try(self._h, int(maxCorners), C.byref(n), C.byref(done)))
+        return n.value if done.value else None
+
     def seg_detect_cancel(self):
         """Abandon detections begun / prepared / staged ahead and never used (icelk_seg_detect_cancel)."""
         self._ck(self._lib.icelk_seg_detect_cancel(self._h))

@@ -38,6 +38,8 @@ struct Ctx {
     // (completion signal of the first, dependency of the second: 220 us copies came out 270 us apart), which a copy
     // queued on the other stream fills
     hipStream_t copy_stream2 = nullptr;
+    hipStream_t copy_more[2] = {nullptr, nullptr};   // ICELK_COPY_STREAMS=3|4 (A/B measurements)
+    int n_copy_streams = 2;
     unsigned upload_seq = 0;
     // pyramids built ahead of their step: not on the copy stream, where a 12 MB upload of a LATER frame would stand
     // between a pyramid and the tracker launch that waits for it
@@ -662,6 +664,11 @@ static void destroy_ctx(Ctx* c)
         hipStreamSynchronize(c->copy_stream2);
         hipStreamDestroy(c->copy_stream2);
     }
+    for (auto q : c->copy_more)
+        if (q) {
+            hipStreamSynchronize(q);
+            hipStreamDestroy(q);
+        }
     if (c->pyr_stream) {
         hipStreamSynchronize(c->pyr_stream);
         hipStreamDestroy(c->pyr_stream);
@@ -1386,6 +1393,14 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
             (rc = dmalloc(c, &S.order_border, 1)) || (rc = dmalloc(c, &S.tracks, np * kMaxVert * 2)) ||
             (rc = dmalloc(c, &S.quality, np * (kMaxVert - 1))))
             return fail(rc);
+    if (const char* ncs = getenv("ICELK_COPY_STREAMS")) {
+        c->n_copy_streams = std::min(std::max(atoi(ncs), 1), 4);
+        for (int k = 2; k < c->n_copy_streams; k++)
+            if (hipStreamCreateWithFlags(&c->copy_more[k - 2], hipStreamNonBlocking) != hipSuccess) {
+                c->err = "hipStreamCreate failed";
+                return fail(ICELK_EHIP);
+            }
+    }
     c->use_order = getenv("ICELK_NO_ORDER") == nullptr;
     c->border_first = getenv("ICELK_NO_BORDER_FIRST") == nullptr;
     c->pyr_per_level = getenv("ICELK_PYR_PER_LEVEL") != nullptr;
@@ -1485,6 +1500,8 @@ int icelk_sync(icelk_t* h)
     // (icelk_seg_detect_prepare), the min-distance / sort / emit stage, tracker launches
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream2));
+    for (auto q : c->copy_more)
+        if (q) HIPCHK(c, hipStreamSynchronize(q));
     HIPCHK(c, hipStreamSynchronize(c->pyr_stream));
     HIPCHK(c, hipStreamSynchronize(c->eig_stream));
     HIPCHK(c, hipStreamSynchronize(c->det_stream));
@@ -1539,7 +1556,8 @@ int icelk_upload_gray_async(icelk_t* h, int slot, const uint8_t* pinned_host, in
     int rc = begin_frame(c, slot, w, h_);
     if (rc) return rc;
     Slot& s = c->slots[slot];
-    const hipStream_t cs = (c->upload_seq++ & 1) ? c->copy_stream2 : c->copy_stream;
+    const unsigned useq = c->upload_seq++ % (unsigned)c->n_copy_streams;
+    const hipStream_t cs = useq == 0 ? c->copy_stream : (useq == 1 ? c->copy_stream2 : c->copy_more[useq - 2]);
     // the copy must not overtake the launches that still read this slot (Slot::used / det_used)
     if (int rcw = wait_event(c, cs, s.used)) return rcw;
     if (s.pending) if (int rcw = wait_event(c, cs, s.ready)) return rcw;   // an upload or a pyramid built ahead still in flight
@@ -2087,6 +2105,28 @@ int icelk_seg_detect_stage(icelk_t* h, int max_corners, int* out_n)
     Ctx* c = C(h);
     HIPCHK(c, hipSetDevice(c->device));
     return seg_stage(c, max_corners, out_n);
+}
+
+int icelk_seg_detect_stage_try(icelk_t* h, int max_corners, int* out_n, int* out_done)
+{
+    if (!h || !out_done) return ICELK_EARG;
+    Ctx* c = C(h);
+    HIPCHK(c, hipSetDevice(c->device));
+    *out_done = 0;
+    if (c->seg_staged) FAIL(c, ICELK_ESTATE, "a staged segment is waiting for icelk_seg_switch");
+    const int k = det_oldest(c);
+    if (k < 0) FAIL(c, ICELK_ESTATE, "no detection in flight");
+    // the counts of the oldest detection in flight: published behind its min-distance stage (publish_counts)
+    const hipError_t q = hipEventQuery(c->dset[k].counts_ev);
+    if (q == hipErrorNotReady) {
+        (void)hipGetLastError();
+        return ICELK_OK;
+    }
+    HIPCHK(c, q);
+    int rc = seg_stage(c, max_corners, out_n);
+    if (rc) return rc;
+    *out_done = 1;
+    return ICELK_OK;
 }
 
 int icelk_seg_switch(icelk_t* h)

@@ -191,6 +191,12 @@ int icelk_seg_detect_cancel(icelk_t* h);
  * _switch of that step), the one host round trip of a detection is off the critical path: the tracker launch of
  * frame c finds its segment ready.  _finish == _stage followed by _switch. */
 int icelk_seg_detect_stage(icelk_t* h, int max_corners, int* out_n);
+/* _stage that never waits: *out_done = 0 (and nothing done) while the kernels of the oldest detection in flight have
+ * not delivered their counts yet, else _stage (*out_done = 1).  A loop that looks ahead calls this at every step from
+ * the first one at which the detection may be through, and the waiting form only when the segment is needed at the
+ * next step: the host thread -- which also issues the uploads and the tracker launches -- then never stands behind the
+ * detector's kernels (with the waiting form it stood there for a third of every period of the PCIe-fed loop). */
+int icelk_seg_detect_stage_try(icelk_t* h, int max_corners, int* out_n, int* out_done);
 int icelk_seg_switch(icelk_t* h);
 /* Optional, ahead of _begin: produce the corner candidates (min-eigenvalue map + non-max test, the part of
  * s1:437 that depends on nothing but the frame and blockSize) of a frame that is already in `slot`, on a stream of

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""From a rocprofv3 kernel trace of bench.py: the kernels of two steady-state steps, one line each (start relative to
-the first tracker launch shown, duration, queue), then how much of the span the tracker launches cover."""
+"""From a rocprofv3 kernel trace of `bench.py --no-kernel-timing` (no per-kernel "alone" launches behind the timed region:
+the last tracker launches of the trace ARE timed steps): the kernels of a few steady-state steps, one line each (start
+relative to the first tracker launch shown, duration, queue), then how much of the steady-state span the tracker launches
+cover and the gaps between consecutive tracker launches."""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True)[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")) for r in csv.DictReader(open(f))]
