@@ -636,28 +636,45 @@ def main():
                 vi = pj.get("lk_fb_valu_insts_per_launch")
                 if vi:
                     vi *= scale
-                    rate = vi / (out["roofline"]["avg_launch_us"] * 1e-6)
-                    cyc = pj.get("valu_cycles_per_inst", {})
-                    out["roofline"]["valu_issue"] = {
-                        "wave_instructions_per_launch": vi, "salu_instructions_per_launch": (pj.get("lk_fb_salu_insts_per_launch") or 0) * scale,
-                        "achieved_per_s": rate,
-                        "peak_per_s": {k: SIMDS * CLOCK_HZ / v for k, v in cyc.items()},
-                        "frac": {k: rate / (SIMDS * CLOCK_HZ / v) for k, v in cyc.items()},
-                        "peak_source": pj.get("valu_cycles_source"),
-                        "valu_busy_pct": pj.get("lk_fb_valu_busy_pct"), "lds_bank_conflict_ratio": pj.get("lk_fb_lds_bank_conflict_ratio"),
-                        "waves_per_simd": pj.get("lk_fb_waves_per_simd"), "vgprs": pj.get("lk_fb_vgprs"),
-                        "sgpr_spills": pj.get("lk_fb_sgpr_spills")}
+                    launch_s = out["roofline"]["avg_launch_us"] * 1e-6
+                    rate = vi / launch_s
+                    mixes = pj.get("valu_mix") or {}
+                    trk_mix = mixes.get("tracker")
+                    vio = {"wave_instructions_per_launch": vi,
+                           "salu_instructions_per_launch": (pj.get("lk_fb_salu_insts_per_launch") or 0) * scale,
+                           "achieved_per_s": rate,
+                           # hardware counter of the profiled run: quad-cycles in which a SIMD issued a VALU instruction / all
+                           # SIMD cycles of the launch -- a fraction <= 1 by construction
+                           "valu_busy_counter_frac": (pj.get("lk_fb_valu_busy_pct") or 0) / 100.0 or None,
+                           "lds_bank_conflict_ratio": pj.get("lk_fb_lds_bank_conflict_ratio"),
+                           "waves_per_simd": pj.get("lk_fb_waves_per_simd"), "vgprs": pj.get("lk_fb_vgprs"),
+                           "sgpr_spills": pj.get("lk_fb_sgpr_spills"), "counters_note": pj.get("counters_note")}
+                    if trk_mix:
+                        # the peak for THIS instruction mix: measured issue time of each class x its share in the kernel's hot
+                        # blocks (profiles/r03_isa_mix_*.json, profiles/valu_class_cost.json)
+                        peak = SIMDS / (trk_mix["ns_per_valu_inst"] * 1e-9)
+                        vio["mix_weighted"] = {"ns_per_inst_per_simd": trk_mix["ns_per_valu_inst"], "peak_per_s": peak,
+                                               "frac": rate / peak, "accounting_error": bool(rate / peak > 1.0),
+                                               "hot_class_share": trk_mix["hot_class_share"], "mix_source": trk_mix["source"],
+                                               "class_cost_source": mixes.get("class_cost_source")}
+                    out["roofline"]["valu_issue"] = vio
                     bes = pj.get("beside_valu_insts_per_launch")
-                    if bes and bes.get("k_eig_nms") and cname in ("c2", "c3", "c4") and lkp["pairs_per_launch"] > 1.5:
-                        # everything the SIMDs issue per period of the pipeline (two frames: one joint tracker launch,
-                        # one corner kernel, two pyramids, one min-distance chain) against the wall time of that period
-                        per_period = vi + bes["k_eig_nms"] + 2 * (bes.get("k_pyramid_ahead") or 0) + (bes.get("min_distance_chain") or 0)
+                    if bes and bes.get("k_eig_nms") and trk_mix and cname in ("c2", "c3", "c4") and lkp["pairs_per_launch"] > 1.5:
+                        # everything the SIMDs issue per period of the pipeline (two frames: one joint tracker launch, one
+                        # corner kernel, two pyramids, one min-distance chain), each kernel priced with its own mix, against
+                        # the wall time of that period
+                        ns = lambda key: ((mixes.get(key) or trk_mix)["ns_per_valu_inst"])   # noqa: E731
+                        parts = {"tracker": (vi, ns("tracker")), "corner_kernel": (bes["k_eig_nms"], ns("corner_kernel")),
+                                 "pyramids": (2 * (bes.get("k_pyramid_ahead") or 0), ns("pyramid_one_wave")),
+                                 "min_distance_chain": (bes.get("min_distance_chain") or 0, ns("tracker"))}
                         period_s = lkp["pairs_per_launch"] / out["value"]
+                        t_min = sum(n * c for n, c in parts.values()) * 1e-9 / SIMDS
                         out["roofline"]["valu_issue"]["pipeline"] = {
-                            "wave_instructions_per_period": per_period, "period_us": period_s * 1e6,
-                            "achieved_per_s": per_period / period_s,
-                            "frac": {k: per_period / period_s / (SIMDS * CLOCK_HZ / v) for k, v in cyc.items()},
-                            "note": "tracker + corner kernel + pyramids + min-distance chain share the SIMDs: the pipeline as a whole is at the issue limit"}
+                            "wave_instructions_per_period": {k: n for k, (n, _) in parts.items()}, "period_us": period_s * 1e6,
+                            "issue_time_at_peak_us": t_min * 1e6, "frac": t_min / period_s,
+                            "accounting_error": bool(t_min / period_s > 1.0),
+                            "note": "tracker + corner kernel + pyramids + min-distance chain share the SIMDs: time the period's "
+                                    "instructions need at the measured issue rate of their classes / wall time of the period"}
             except Exception as exc:
                 sys.stderr.write("profiles/pmc_%s.json unreadable: %s\n" % (cname, exc))
         if world == 1 and not args.no_cpu_baseline:

@@ -60,6 +60,7 @@ SIGNATURES = {
     "icelk_seg_detect_begin": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
     "icelk_seg_detect_finish": (C.c_int, [handle_p, C.c_int, i32p]),
     "icelk_seg_detect_cancel": (C.c_int, [handle_p]),
+    "icelk_set_variant": (C.c_int, [handle_p, C.c_char_p, C.c_int]),
     "icelk_seg_detect_stage_try": (C.c_int, [handle_p, C.c_int, i32p, i32p]),
     "icelk_detect_fast_stats": (C.c_int, [handle_p, C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
     "icelk_seg_detect_stage": (C.c_int, [handle_p, C.c_int, i32p]),

@@ -88,6 +88,11 @@ class Context:
         """0 = default, LK_GENERIC_KERNEL or LK_MULTI_PER_WAVE: the three tracker kernels give identical results."""
         self._ck(self._lib.icelk_set_lk_kernel(self._h, int(which)))
 
+    def set_variant(self, name, value):
+        """A named build-dependent variant of OpenCV's arithmetic: "lk_sums" 0|1|2, "sobel_fma" 0..3, "eig_fma" 0|1
+        (icelk_set_variant; 0 = default).  The oracle has the same switches (oracle.set_variant)."""
+        self._ck(self._lib.icelk_set_variant(self._h, name.encode(), int(value)))
+
     def set_fb_distance(self, form):
         """FB_HYPOT (np.hypot on float32, s1:330; default) or FB_SQRT ((dx**2+dy**2)**0.5, s0_1:99)."""
         self._ck(self._lib.icelk_set_fb_distance(self._h, int(form)))

@@ -158,6 +158,8 @@ struct Ctx {
     // single retiring tracker wave (k_pyramid.hip); ICELK_PYR_AHEAD_WIDE=1 keeps the 256-thread geometry there too (A/B)
     bool pyr_ahead_one_wave = true;
     int fb_dist_form = ICELK_FB_HYPOT;     // icelk_set_fb_distance
+    int lk_sum_mode = 0;                   // icelk_set_variant "lk_sums"
+    int corner_variant = 0;                // icelk_set_variant "sobel_fma" (bits 0-1) | "eig_fma" (bit 2)
     int lk_kernel_flags = 0;               // icelk_set_lk_kernel: ICELK_FLAG_GENERIC_KERNEL / _ONE_PER_WAVE or 0
     // diagnostics: ICELK_LK_STAMPS=<file> records entry / exit time and placement of every workgroup of the LAST
     // segment tracker launch and writes them to the file when the handle is destroyed (tools/lk_stamps.py reads it)
@@ -443,6 +445,7 @@ static int make_lk_params(Ctx* c, int w, int h, int win_w, int win_h, int max_le
     P->fb_thr = fb_thr;
     P->margin = 6;
     P->dist_form = c->fb_dist_form;
+    P->sum_mode = c->lk_sum_mode;
     return ICELK_OK;
 }
 
@@ -810,7 +813,7 @@ static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
 {
     int rc = check_slot(c, slot, true);
     if (rc) return rc;
-    if (!fused_block_size(block_size) || getenv("ICELK_GENERIC_CORNERS")) return ICELK_OK;
+    if (!fused_block_size(block_size) || getenv("ICELK_GENERIC_CORNERS") || c->corner_variant) return ICELK_OK;
     Slot& s = c->slots[slot];
     const uint8_t* mask = nullptr;
     if (use_mask) {
@@ -900,7 +903,7 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
     // reset its counters on the tail stream) must be through
     if (int rcw = wait_event(c, ds, s.frame_ev)) return rcw;   // level 0 only (see detect_prepare)
     if (int rcw = wait_event(c, ds, c->tail_done)) return rcw;
-    const bool generic = getenv("ICELK_GENERIC_CORNERS") != nullptr;
+    const bool generic = getenv("ICELK_GENERIC_CORNERS") != nullptr || c->corner_variant != 0;
     // counters are normally left zeroed by the previous detection (the reset runs after its last kernel,
     // off the critical path); reset here only the first time or when the cell grid grew
     const bool need_reset = !c->counters_clean || ncell > c->reset_ncell;
@@ -928,7 +931,7 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
         if (int rcw = wait_event(c, ds, spare.done)) return rcw;
         HIPCHK(c, hipMemsetAsync(spare.max_key, 0, sizeof(unsigned), ds));
         if (need_reset) launch_detect_reset(ds, D, (int)ncell, 1);
-        launch_candidates(ds, D, s.lv[0], block_size, mask, c->mask_pitch, quality, generic, nullptr);
+        launch_candidates(ds, D, s.lv[0], block_size, mask, c->mask_pitch, quality, generic, nullptr, c->corner_variant);
         HIPCHK(c, hipEventRecord(s.det_used, ds));   // nothing after this launch reads the frame
     }
     c->counters_clean = false;
@@ -1151,7 +1154,7 @@ static bool same_lk_params(const LKParams& a, const LKParams& b)
 {
     return a.win_w == b.win_w && a.win_h == b.win_h && a.top_level == b.top_level && a.max_count == b.max_count &&
            a.eps2 == b.eps2 && a.flags == b.flags && a.min_eig_thr == b.min_eig_thr && a.fb_thr == b.fb_thr &&
-           a.margin == b.margin && a.dist_form == b.dist_form;
+           a.margin == b.margin && a.dist_form == b.dist_form && a.sum_mode == b.sum_mode;
 }
 
 // shared by icelk_seg_track / icelk_seg_track_async / icelk_seg_track_defer
@@ -1517,6 +1520,18 @@ int icelk_set_lk_kernel(icelk_t* h, int which)
     if (which != 0 && which != ICELK_FLAG_GENERIC_KERNEL && which != ICELK_FLAG_MULTI_PER_WAVE)
         FAIL(c, ICELK_EARG, "bad kernel selector");
     c->lk_kernel_flags = which;
+    return ICELK_OK;
+}
+
+int icelk_set_variant(icelk_t* h, const char* name, int value)
+{
+    if (!h || !name) return ICELK_EARG;
+    Ctx* c = C(h);
+    if (!strcmp(name, "lk_sums") && value >= 0 && value <= 2) c->lk_sum_mode = value;
+    else if (!strcmp(name, "sobel_fma") && value >= 0 && value <= 3) c->corner_variant = (c->corner_variant & 4) | value;
+    else if (!strcmp(name, "eig_fma") && (value == 0 || value == 1)) c->corner_variant = (c->corner_variant & 3) | (value << 2);
+    else FAIL(c, ICELK_EARG, "unknown variant / value");
+    for (auto& e : c->eo) e.valid = false;     // candidates prepared under another variant are not adopted
     return ICELK_OK;
 }
 
@@ -1969,10 +1984,10 @@ int icelk_min_eig_map(icelk_t* h, int slot, int block_size, float* host_out, int
         ProfScope p(c, K_EIG);
         launch_detect_reset(c->stream, c->D, 0, 3);
         c->counters_clean = false;
-        if (fused_block_size(block_size) && !getenv("ICELK_GENERIC_CORNERS")) {
+        if (fused_block_size(block_size) && !getenv("ICELK_GENERIC_CORNERS") && !c->corner_variant) {
             launch_candidates(c->stream, c->D, s.lv[0], block_size, nullptr, 0, 1.0, false, c->D.eig);
         } else {
-            launch_min_eig(c->stream, s.lv[0], block_size, c->D.eig, nullptr, 0, c->D.max_key);
+            launch_min_eig(c->stream, s.lv[0], block_size, c->D.eig, nullptr, 0, c->D.max_key, c->corner_variant);
         }
     }
     rc = check_launch(c, "min_eig");

@@ -34,6 +34,10 @@ struct LKParams {
     int margin;         // search-region margin R of the LDS-staged J tile
     float eps2_lo, eps2_hi;   // float values below / above which (double)dx*dx + (double)dy*dy <= eps2 is decided
     int dist_form;      // forward-backward distance: 0 = np.hypot on float32 (s1:330), 1 = (dx^2+dy^2)^0.5 (s0_1:99)
+    // how A11, A12, A22, b1, b2 are summed (icelk_set_variant "lk_sums"): 0 = exactly (int64), one rounding; 1 / 2 = in the
+    // float lanes of OpenCV 3.x's SSE2 block / 4.x's CV_SIMD128 block (oracle/icelk_oracle.c orc_set_variant).  Non-zero
+    // runs in the window-generic kernel only.
+    int sum_mode;
 };
 
 // kernel ids for the profiling table
@@ -168,14 +172,14 @@ struct DetectScratch {
     unsigned* aties;         // pixels (y << 16 | x) whose neighbourhood the exact pass must look at; 0x80000000 | tile: whole tile
 };
 void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig, const uint8_t* mask,
-                    int mask_pitch, unsigned* max_key);
+                    int mask_pitch, unsigned* max_key, int variant = 0);
 bool fused_block_size(int bs);
 // mode: 0 = the cell grid and the counters; | 1 = the key histogram too; | 2 = and the masked maximum D.max_key (only where
 // the candidate buffer behind it is known to be this detection's: it may have been handed on since)
 void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, int mode);
 // K6+K7: local maxima into per-workgroup regions of D.raw (stream order, no host sync)
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
-                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null);
+                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null, int variant = 0);
 // K6 + K7 in two passes for blockSize 3 / 5 / 7 / 10 (integer bracket of the map, exact arithmetic at the possible maxima
 // only): same regions, counts and max_key as launch_candidates' one-pass kernel.  quality <= 0: no threshold cut.
 bool launch_candidates_fast(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,

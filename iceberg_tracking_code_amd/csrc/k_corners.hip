@@ -66,13 +66,24 @@ __device__ __forceinline__ float threshold_of(const unsigned* max_key, double qu
 // Sobel (ksize 3) pair scaled as cornerEigenValsVecs does, in OpenCV's operation order:
 //   Dx: row pass [-1 0 1] (exact), column pass (r0 + r2)*k1 + r1*k0
 //   Dy: row pass k1*a + k0*b + k1*c left to right, column pass t2 - t0
-__device__ __forceinline__ void sobel_cov(float a0, float b0, float c0, float a1, float c1, float a2, float b2,
-                                          float c2, float k0, float k1, float& xx, float& xy, float& yy)
+// `variant` (icelk_set_variant, the generic kernel only): bit 0 = the symmetric column pass fused, fmaf(r0 + r2, k1, r1 k0)
+// (OpenCV 4.x SymmColumnSmallVec_32f in an FMA3 build); bit 1 = the row pass with its two additions fused (a RowFilter loop
+// contracted by a compiler that targets FMA); bit 2 = calcMinEigenVal's (a-c)^2 + b^2 as fmaf(b, b, t t).  0 = what every
+// other kernel computes.  oracle/icelk_oracle.c names the same switches (orc_set_variant).
+__device__ __forceinline__ float row_smooth(float a, float b, float c, float k0, float k1, int variant)
 {
-    const float dx = __fadd_rn(__fmul_rn(__fadd_rn(__fsub_rn(c0, a0), __fsub_rn(c2, a2)), k1),
-                               __fmul_rn(__fsub_rn(c1, a1), k0));
-    const float t0 = __fadd_rn(__fadd_rn(__fmul_rn(k1, a0), __fmul_rn(k0, b0)), __fmul_rn(k1, c0));
-    const float t2 = __fadd_rn(__fadd_rn(__fmul_rn(k1, a2), __fmul_rn(k0, b2)), __fmul_rn(k1, c2));
+    if (variant & 2) return fmaf(k1, c, fmaf(k0, b, __fmul_rn(k1, a)));
+    return __fadd_rn(__fadd_rn(__fmul_rn(k1, a), __fmul_rn(k0, b)), __fmul_rn(k1, c));
+}
+
+__device__ __forceinline__ void sobel_cov(float a0, float b0, float c0, float a1, float c1, float a2, float b2,
+                                          float c2, float k0, float k1, float& xx, float& xy, float& yy, int variant = 0)
+{
+    const float dx = (variant & 1) ? fmaf(__fadd_rn(__fsub_rn(c0, a0), __fsub_rn(c2, a2)), k1, __fmul_rn(__fsub_rn(c1, a1), k0))
+                                   : __fadd_rn(__fmul_rn(__fadd_rn(__fsub_rn(c0, a0), __fsub_rn(c2, a2)), k1),
+                                               __fmul_rn(__fsub_rn(c1, a1), k0));
+    const float t0 = row_smooth(a0, b0, c0, k0, k1, variant);
+    const float t2 = row_smooth(a2, b2, c2, k0, k1, variant);
     const float dy = __fsub_rn(t2, t0);
     xx = __fmul_rn(dx, dx);
     xy = __fmul_rn(dx, dy);
@@ -123,11 +134,12 @@ __device__ __forceinline__ void window_sums(const double (&v)[N + BS - 1], doubl
     }
 }
 
-__device__ __forceinline__ float min_eig_of(double s0, double s1, double s2)
+__device__ __forceinline__ float min_eig_of(double s0, double s1, double s2, int variant = 0)
 {
     const float a = __fmul_rn((float)s0, 0.5f), b = (float)s1, c = __fmul_rn((float)s2, 0.5f);
     const float d = __fsub_rn(a, c);
-    return __fsub_rn(__fadd_rn(a, c), sqrtf(__fadd_rn(__fmul_rn(d, d), __fmul_rn(b, b))));
+    const float r = (variant & 4) ? fmaf(b, b, __fmul_rn(d, d)) : __fadd_rn(__fmul_rn(d, d), __fmul_rn(b, b));
+    return __fsub_rn(__fadd_rn(a, c), sqrtf(r));
 }
 
 // wave-reduce `best` and publish it; the atomic is skipped when the published maximum is already as large
@@ -401,7 +413,7 @@ constexpr int EIG_TH = 16;
 __global__ __launch_bounds__(256) void k_min_eig(const uint8_t* __restrict__ img, int w, int h, int pitch, int bs,
                                                  float k0, float k1, float* __restrict__ eig,
                                                  const uint8_t* __restrict__ mask, int mask_pitch,
-                                                 unsigned* __restrict__ max_key)
+                                                 unsigned* __restrict__ max_key, int variant)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int anchor = bs / 2;
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(256) void k_min_eig(const uint8_t* __restrict__ img
         const uint8_t* r2 = img + (size_t)yp * pitch;
         float xx, xy, yy;
         sobel_cov((float)r0[xm], (float)r0[rx], (float)r0[xp], (float)r1[xm], (float)r1[xp], (float)r2[xm],
-                  (float)r2[rx], (float)r2[xp], k0, k1, xx, xy, yy);
+                  (float)r2[rx], (float)r2[xp], k0, k1, xx, xy, yy, variant);
         cov[i] = xx;
         cov[ew * eh + i] = xy;
         cov[2 * ew * eh + i] = yy;
@@ -452,7 +464,7 @@ __global__ __launch_bounds__(256) void k_min_eig(const uint8_t* __restrict__ img
             s1 += r[eh * EIG_TW + k * EIG_TW];
             s2 += r[2 * eh * EIG_TW + k * EIG_TW];
         }
-        const float v = min_eig_of(s0, s1, s2);
+        const float v = min_eig_of(s0, s1, s2, variant);
         eig[(size_t)y * w + x] = v;
         if (!mask || mask[(size_t)y * mask_pitch + x]) {
             const unsigned k = ordered_key(v);
@@ -850,7 +862,7 @@ size_t candidate_blocks(int w, int h)
 
 // K6 alone, writing the map with the any-blockSize kernel.
 void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig, const uint8_t* mask,
-                    int mask_pitch, unsigned* max_key)
+                    int mask_pitch, unsigned* max_key, int variant)
 {
     float k0, k1;
     sobel_scale(block_size, &k0, &k1);
@@ -863,7 +875,7 @@ void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig,
     }
     dim3 grid((img.w + EIG_TW - 1) / EIG_TW, (img.h + EIG_TH - 1) / EIG_TH);
     hipLaunchKernelGGL(k_min_eig, grid, dim3(256), lds, s, img.ptr, img.w, img.h, img.pitch, block_size, k0, k1, eig,
-                       mask, mask_pitch, max_key);
+                       mask, mask_pitch, max_key, variant);
 }
 
 static CandSrc src_of(const DetectScratch& D)
@@ -890,8 +902,9 @@ void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, int mode)
 
 // Candidate collection (K6+K7) into regions of D.raw (stream order, no host sync).
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
-                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null)
+                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null, int variant)
 {
+    if (variant) use_generic = true;     // the named variants live in the any-blockSize kernel only
     unsigned long long* raw = D.raw;
     CandSrc g_src{};
     // ICELK_TWO_PASS_CORNERS=1: the two-pass form (k_corners_fast.hip: integer bracket of the map + exact arithmetic at the
@@ -910,7 +923,7 @@ void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int bl
             default: launch_fused<10>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
         }
     } else {
-        launch_min_eig(s, img, block_size, D.eig, mask, mask_pitch, D.max_key);
+        launch_min_eig(s, img, block_size, D.eig, mask, mask_pitch, D.max_key, variant);
         g_src.keys = raw;
         g_src.blk_count = D.blk_count;
         g_src.nblk = 0;

@@ -111,6 +111,33 @@ __device__ __forceinline__ TrackResult track_point(const Pyramid& PI, const Pyra
     R.err = 0.f;
     R.iters = 0;
     float sx = 0.f, sy = 0.f;  // the stored nextPts value
+    // LKParams::sum_mode != 0: the sums in the float lanes of OpenCV's x86 SIMD blocks.  Every pixel's products go to LDS
+    // in raster order; chain c < 4 of a plane adds the products of the columns x = c (mod 4) below `whole` row by row, chain
+    // 4 those of the columns from `whole` on (the scalar tail of a row), each one float addition at a time in raster order
+    // -- the order the SSE2 / CV_SIMD128 loops add them in (oracle/icelk_oracle.c lanes_a_row, lanes_b_px).  A lane per
+    // chain; the five chains of a plane are folded as the blocks fold their lanes.
+    float* fsum = reinterpret_cast<float*>(lds + plan.deriv_off + 4 * (win_w + 1) * (win_h + 1));
+    auto lane_chain_sums = [&](int planes, int whole, bool pairwise, float (&out)[3]) {
+        __syncthreads();
+        float acc = 0.f;
+        if (lane < 5 * planes) {
+            const int p = lane / 5, c = lane - 5 * p;
+            const float* src = fsum + p * npx;
+            for (int y = 0; y < win_h; y++) {
+                if (c < 4) for (int x = c; x < whole; x += 4) acc = __fadd_rn(acc, src[y * win_w + x]);
+                else for (int x = whole; x < win_w; x++) acc = __fadd_rn(acc, src[y * win_w + x]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            if (p >= planes) break;
+            const float q0 = __shfl(acc, 5 * p), q1 = __shfl(acc, 5 * p + 1), q2 = __shfl(acc, 5 * p + 2), q3 = __shfl(acc, 5 * p + 3);
+            const float t = __shfl(acc, 5 * p + 4);
+            out[p] = pairwise ? __fadd_rn(t, __fadd_rn(__fadd_rn(q0, q2), __fadd_rn(q1, q3)))
+                              : __fadd_rn(t, __fadd_rn(__fadd_rn(__fadd_rn(q0, q1), q2), q3));
+        }
+        __syncthreads();
+    };
 
     for (int level = P.top_level; level >= 0; level--) {
         const Level LI = PI.lv[level];
@@ -180,11 +207,23 @@ __device__ __forceinline__ TrackResult track_point(const Pyramid& PI, const Pyra
                 a11 += ixv * ixv;
                 a12 += ixv * iyv;
                 a22 += iyv * iyv;
+                if (P.sum_mode) {
+                    const int idx = lane + 64 * k;
+                    fsum[idx] = (float)(ixv * ixv);
+                    fsum[npx + idx] = (float)(ixv * iyv);
+                    fsum[2 * npx + idx] = (float)(iyv * iyv);
+                }
             }
         }
-        const float A11 = (float)wave_sum_exact(a11) * FLT_SCALE;
-        const float A12 = (float)wave_sum_exact(a12) * FLT_SCALE;
-        const float A22 = (float)wave_sum_exact(a22) * FLT_SCALE;
+        float A11 = (float)wave_sum_exact(a11) * FLT_SCALE;
+        float A12 = (float)wave_sum_exact(a12) * FLT_SCALE;
+        float A22 = (float)wave_sum_exact(a22) * FLT_SCALE;
+        if (P.sum_mode) {
+            // 3.x: groups of 4 pixels, lanes folded ((l0+l1)+l2)+l3; 4.x: groups of 8, folded (l0+l2)+(l1+l3)
+            float o[3];
+            lane_chain_sums(3, P.sum_mode == 1 ? (win_w & ~3) : (win_w & ~7), P.sum_mode == 2, o);
+            A11 = __fmul_rn(o[0], FLT_SCALE); A12 = __fmul_rn(o[1], FLT_SCALE); A22 = __fmul_rn(o[2], FLT_SCALE);
+        }
         float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
         const float dif = __fsub_rn(A11, A22);
         const float rad = __fadd_rn(__fmul_rn(dif, dif), __fmul_rn(__fmul_rn(4.f, A12), A12));
@@ -227,10 +266,21 @@ __device__ __forceinline__ TrackResult track_point(const Pyramid& PI, const Pyra
                                              W_BITS - 5) - Ival[k];
                     b1 += diff * (int)(short)(dIval[k] & 0xffff);
                     b2 += diff * ((int)dIval[k] >> 16);
+                    if (P.sum_mode) {
+                        const int idx = lane + 64 * k;
+                        fsum[idx] = (float)(diff * (int)(short)(dIval[k] & 0xffff));      // int32 -> float, as _mm_cvtepi32_ps
+                        fsum[npx + idx] = (float)(diff * ((int)dIval[k] >> 16));
+                    }
                 }
             }
-            const float fb1 = (float)wave_sum_exact(b1) * FLT_SCALE;
-            const float fb2 = (float)wave_sum_exact(b2) * FLT_SCALE;
+            float fb1 = (float)wave_sum_exact(b1) * FLT_SCALE;
+            float fb2 = (float)wave_sum_exact(b2) * FLT_SCALE;
+            if (P.sum_mode) {
+                // both versions: groups of 8 pixels in 2 x 4 lanes; (q0[k] + q1[k]) pairs = chains (0 + 2) + (1 + 3)
+                float o[3];
+                lane_chain_sums(2, win_w & ~7, true, o);
+                fb1 = __fmul_rn(o[0], FLT_SCALE); fb2 = __fmul_rn(o[1], FLT_SCALE);
+            }
             const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
             const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
             nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
@@ -328,7 +378,8 @@ void launch_ppl(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffe
 size_t lk_lds_bytes(const LKParams& P)
 {
     const LdsPlan p = make_plan(P.win_w, P.win_h, P.margin);
-    return (size_t)p.deriv_off + 4u * (size_t)(P.win_w + 1) * (P.win_h + 1);
+    const size_t lane_sums = P.sum_mode ? 12u * (size_t)P.win_w * P.win_h : 0u;     // three planes of float products
+    return (size_t)p.deriv_off + 4u * (size_t)(P.win_w + 1) * (P.win_h + 1) + lane_sums;
 }
 
 // Returns 0 or ICELK_EARG when the window needs more than 64 pixels per lane (> 4096 px).
@@ -340,9 +391,10 @@ int launch_lk(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers
     // several-features-per-wave form (k_lk_multi.hip: a third fewer vector instructions per feature, but 2-3 waves per
     // SIMD instead of 4 -- measured slower at 21x21, profiles/r02_lk_kernels.txt; kept as a third statement of the
     // arithmetic and for window sizes / chips where the balance tips)
-    if ((P.flags & ICELK_FLAG_MULTI_PER_WAVE) && !(P.flags & ICELK_FLAG_GENERIC_KERNEL) && launch_lk_multi(s, I, J, B, n, P, fb))
+    const bool generic = (P.flags & ICELK_FLAG_GENERIC_KERNEL) || P.sum_mode != 0;
+    if ((P.flags & ICELK_FLAG_MULTI_PER_WAVE) && !generic && launch_lk_multi(s, I, J, B, n, P, fb))
         return ICELK_OK;
-    if (!(P.flags & ICELK_FLAG_GENERIC_KERNEL) && launch_lk_fast(s, I, J, B, n, P, fb)) return ICELK_OK;
+    if (!generic && launch_lk_fast(s, I, J, B, n, P, fb)) return ICELK_OK;
     const int npx = P.win_w * P.win_h;
     const int ppl = (npx + 63) / 64;
     const size_t lds = lk_lds_bytes(P);

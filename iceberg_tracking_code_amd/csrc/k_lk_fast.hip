@@ -330,7 +330,7 @@ bool launch_lk_fast(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKB
 
 bool launch_lk_pair(hipStream_t s, const LKJob& a, const LKJob& b, const LKParams& P)
 {
-    if (P.flags & (ICELK_FLAG_GENERIC_KERNEL | ICELK_FLAG_MULTI_PER_WAVE)) return false;
+    if ((P.flags & (ICELK_FLAG_GENERIC_KERNEL | ICELK_FLAG_MULTI_PER_WAVE)) || P.sum_mode) return false;
     if (a.n <= 0 || b.n <= 0) return false;
     return dispatch_fast(s, a, &b, P, true);
 }

@@ -80,6 +80,18 @@ int icelk_set_lk_kernel(icelk_t* h, int which);
 /* How the fused tracker calls form dist from |p0 - p0r| (ICELK_FB_HYPOT / ICELK_FB_SQRT); the two can differ in
  * the last bit, which flips `valid` for a distance within one ulp of the threshold. */
 int icelk_set_fb_distance(icelk_t* h, int form);
+/* Named variants of the OpenCV semantics that depend on how OpenCV was BUILT (the oracle names the
+ * same switches: oracle/icelk_oracle.c orc_set_variant, and tools/oracle_variants.py measures how far they are apart).
+ * 0 is the default of each and what the tuned kernels compute; a non-zero value routes the call through the
+ * window-generic tracker kernel / the any-blockSize corner kernel, which carry the variants (slower, same interface):
+ *   "lk_sums"    1 | 2   A11, A12, A22, b1, b2 summed in the float lanes of OpenCV 3.x's SSE2 block | 4.x's CV_SIMD128 block
+ *                        instead of exactly (at the reference's own parameters 5 of 40 416 features move by more than
+ *                        1e-3 px between the forms, none changes status)
+ *   "sobel_fma"  bit 0   the Sobel column pass fused (4.x SymmColumnSmallVec_32f in an FMA3 build); bit 1: the row pass fused
+ *   "eig_fma"    1       calcMinEigenVal's (a-c)^2 + b^2 as one fused multiply-add
+ * (the corner SET is the same under all of them on the test frames, the order of near-equal corners changes.)
+ * A cv2 cross-check that finds one of them to be what the reference's OpenCV build does flips this switch. */
+int icelk_set_variant(icelk_t* h, const char* name, int value);
 
 /* ---- frame ingest: replaces cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY) at s1:283,311 / s0_1:71,80 */
 /* host 8-bit gray image -> slot (level 0); invalidates the slot's pyramid. */

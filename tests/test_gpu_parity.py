@@ -449,3 +449,51 @@ def test_two_pass_corner_detector(orc, synth, bs, monkeypatch):
     c.upload_gray(0, img)
     assert np.array_equal(c.good_features(0, 0, 0.007, 10, False, bs), orc.good_features(img, 0, 0.007, 10, None, bs))
     c.close()
+
+
+@pytest.mark.parametrize("name,value", [("lk_sums", 1), ("lk_sums", 2), ("sobel_fma", 1), ("sobel_fma", 2), ("sobel_fma", 3),
+                                        ("eig_fma", 1)])
+def test_named_variants_equal_the_oracles(orc, synth, name, value):
+    """icelk_set_variant: the build-dependent OpenCV semantics SURVEY.md Appendix A asks to keep as named switches -- LK sums
+    in the float lanes of the x86 SIMD blocks (3.x / 4.x), Sobel passes and the eigenvalue term fused -- give, bit for
+    bit, what the oracle gives under the same switch, and differ from the default somewhere (so the switch is live)."""
+    from iceberg_tracking_code_amd import Context
+    w, h = 640, 480
+    img0, img1 = _pair(synth, w, h, 600, -420, 99)
+    c = Context(w, h, n_slots=2, max_pts=1 << 14)
+    c.upload_gray(0, img0)
+    c.upload_gray(1, img1)
+    try:
+        if name == "lk_sums":
+            pts = orc.good_features(img0, 3000, 0.005, 5, None, 5).reshape(-1, 2)
+            base = c.track_fb(0, 1, pts, (21, 21), 3, CRIT_DEFAULT)
+            differs = 0
+            for win, lvl, crit in (((21, 21), 3, CRIT_DEFAULT), ((35, 35), 4, CRIT_REF), ((9, 13), 2, CRIT_DEFAULT)):
+                c.set_variant(name, value)
+                got = c.track_fb(0, 1, pts, win, lvl, crit)
+                c.set_variant(name, 0)
+                with orc.variants(**{name: value}):
+                    ref = orc.track_fb(img0, img1, pts, win, lvl, crit)
+                for k in ("p1", "p0r", "st_fwd", "st_bwd", "err_fwd", "err_bwd", "dist", "valid"):
+                    assert np.array_equal(got[k].view(np.uint8), ref[k].view(np.uint8)), (win, k)
+                if win == (21, 21):
+                    differs = int((got["p1"] != base["p1"]).any(axis=1).sum())
+            assert 0 < differs < len(pts) // 2
+            again = c.track_fb(0, 1, pts, (21, 21), 3, CRIT_DEFAULT)       # back on the default (tuned kernel)
+            assert np.array_equal(again["p1"].view(np.uint32), base["p1"].view(np.uint32))
+        else:
+            base_map = c.min_eig_map(0, 10)
+            c.set_variant(name, value)
+            got_map = c.min_eig_map(0, 10)
+            got = [c.good_features(0, mc, 0.007, 10, False, bs) for mc, bs in ((0, 10), (500, 3))]
+            c.set_variant(name, 0)
+            with orc.variants(**{name: value}):
+                ref_map = orc.min_eig_map(img0, 10)
+                ref = [orc.good_features(img0, mc, 0.007, 10, None, bs) for mc, bs in ((0, 10), (500, 3))]
+            assert np.array_equal(got_map.view(np.uint32), ref_map.view(np.uint32))
+            assert (got_map != base_map).sum() > 100
+            for g, r in zip(got, ref):
+                assert np.array_equal(g, r)
+            assert np.array_equal(c.min_eig_map(0, 10).view(np.uint32), base_map.view(np.uint32))
+    finally:
+        c.close()

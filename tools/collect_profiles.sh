@@ -16,6 +16,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch --
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py $ARGS > $O/pmc_write.log 2>&1
 python3 tools/pmc_summary.py $O/pmc_sq_a $O/pmc_sq_b $O/pmc_fetch $O/pmc_write > $O/pmc_summary.txt 2>&1
 cp $O/trace/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
-python3 tools/timeline_steps.py $O/trace > $O/timeline.txt 2>&1
 grep -h '"metric"' $O/trace.log | tail -1 > $O/bench_under_trace.json
+# the timeline of the TIMED steps: a trace of the run without the per-kernel "alone" launches behind the timed region
+rocprofv3 --kernel-trace --output-format csv -d $O/trace_tl -- python3 bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-kernel-timing $* > $O/trace_tl.log 2>&1
+python3 tools/timeline_steps.py $O/trace_tl > $O/timeline.txt 2>&1
 tail -3 $O/timeline.txt; head -6 $O/kernel_stats.csv | cut -c1-160

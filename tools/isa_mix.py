@@ -100,6 +100,9 @@ def main():
     ap.add_argument("kernel", help="substring of the mangled kernel name")
     ap.add_argument("--blocks", action="store_true")
     ap.add_argument("--json")
+    ap.add_argument("--hot-min", type=int, default=40,
+                    help="basic blocks inside loops with at least this many instructions count as the hot straight-line code "
+                         "(the reflecting border loaders and other cold paths are many small blocks)")
     args = ap.parse_args()
     path = args.source if args.source.endswith(".s") else assemble(os.path.abspath(args.source))
     name, body = kernel_body(open(path).read(), args.kernel)
@@ -121,7 +124,12 @@ def main():
         if d:
             in_loop.update(c)
         per_block.append(dict(label=label, loop_depth=d, n=len(ops), classes=dict(c)))
-    res = dict(kernel=name, total=dict(total), inside_loops=dict(in_loop), instructions=sum(total.values()))
+    hot = collections.Counter()
+    for b in per_block:
+        if b["loop_depth"] and b["n"] >= args.hot_min:
+            hot.update(b["classes"])
+    res = dict(kernel=name, total=dict(total), inside_loops=dict(in_loop), hot_blocks=dict(hot), hot_min=args.hot_min,
+               instructions=sum(total.values()))
     print(json.dumps(res, indent=1))
     if args.blocks:
         for b in per_block:

@@ -61,12 +61,28 @@ def insts(prefix):
 out["beside_valu_insts_per_launch"] = {"k_eig_nms": insts("k_eig_nms"), "k_pyramid_ahead": insts("k_pyramid<3, 64, 64>"),
                                        "min_distance_chain": sum(insts(k) or 0 for k in ("k_key_hist", "k_key_select", "k_cell_count", "k_scan",
                                                                  "k_cell_fill", "k_suppress", "k_gather_accepted", "k_seg_order", "k_seg_init"))}
-res = json.load(open("profiles/r02_lk_resources.json"))
-out.update(lk_fb_vgprs=res["k_lk_fast<21,21,true>"]["vgprs"], lk_fb_waves_per_simd=res["k_lk_fast<21,21,true>"]["waves_per_simd"],
-           lk_fb_sgpr_spills=res["k_lk_fast<21,21,true>"]["sgpr_spills"])
-# cycles per wave64 instruction per SIMD at >= 4 waves per SIMD, by instruction class (profiles/r02_valu_rate.txt)
-out["valu_cycles_per_inst"] = {"add_shift_mov_fma_f32_class": 3.0, "dot2_perm_mad_pk_cvt_f64_class": 4.7}
-out["valu_cycles_source"] = ("tools/ubench/valu_rate.hip -> profiles/r02_valu_rate.txt (16 instructions per loop body by "
-                             "construction, checked in the disassembly; 1024 SIMDs x 2.4 GHz)")
+mw = re.search(r"k_lk_fast<(\d+), (\d+), true>", lk_name)
+win = (mw.group(1), mw.group(2)) if mw else ("21", "21")
+res = json.load(open("profiles/r03_lk_resources.json"))
+rk = "k_lk_fast<%s,%s,true>" % win
+out.update(lk_fb_vgprs=res[rk]["vgprs"], lk_fb_waves_per_simd=res[rk]["waves_per_simd"], lk_fb_sgpr_spills=res[rk]["sgpr_spills"],
+           lk_fb_scratch_bytes=res[rk].get("scratch_bytes"))
+# Mix-weighted VALU issue cost: static instruction classes of the kernel's hot straight-line blocks (tools/isa_mix.py ->
+# profiles/r03_isa_mix_*.json) x the measured issue time of each class (profiles/valu_class_cost.json).  bench.py turns
+# it into the peak the achieved rate is divided by: a fraction above 1 would be an accounting error.
+cost = json.load(open("profiles/valu_class_cost.json"))["ns_per_inst_per_simd"]
+def mix_ns(path):
+    try:
+        hot = json.load(open(path))["hot_blocks"]
+    except (OSError, KeyError):
+        return None
+    v = {k: n for k, n in hot.items() if k.startswith("valu_")}
+    tot = float(sum(v.values()))
+    return dict(ns_per_valu_inst=sum(n * cost[k] for k, n in v.items()) / tot, hot_valu_instructions=int(tot),
+                hot_class_share={k: n / tot for k, n in v.items()}, hot_salu_per_valu=hot.get("salu", 0) / tot, source=path)
+out["valu_mix"] = {"tracker": mix_ns("profiles/r03_isa_mix_lk%s.json" % win[0]), "corner_kernel": mix_ns("profiles/r03_isa_mix_eig10.json"),
+                   "pyramid_one_wave": mix_ns("profiles/r03_isa_mix_pyr64.json"),
+                   "class_cost_source": "profiles/valu_class_cost.json"}
+out["counters_note"] = "counters are from the profiled run named in `source`, not from the run that prints them"
 json.dump(out, open("profiles/pmc_%s.json" % cfg, "w"), indent=1)
 print(json.dumps(out, indent=1))
