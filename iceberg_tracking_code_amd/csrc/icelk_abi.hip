@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <mutex>
 
@@ -224,6 +226,41 @@ static int check_launch(Ctx* c, const char* what)
     return ICELK_OK;
 }
 
+// ---- roctx ranges (tracing) --------------------------------------------------------------------
+// ICELK_ROCTX=1: the host calls of the frame loop appear as named ranges in a rocprofv3 --marker-trace (tracker launch,
+// detection begin / stage, candidates ahead, pyramid ahead, upload).  The marker library is looked up at run time
+// (librocprofiler-sdk-roctx.so, else libroctx64.so): no link-time dependency, nothing is called when the variable is unset.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        if (!getenv("ICELK_ROCTX")) return;
+        void* lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!push || !pop) push = nullptr;
+    }
+};
+static Roctx& roctx()
+{
+    static Roctx r;
+    return r;
+}
+struct Range {
+    bool on;
+    explicit Range(const char* name) : on(roctx().push != nullptr)
+    {
+        if (on) roctx().push(name);
+    }
+    ~Range()
+    {
+        if (on) roctx().pop();
+    }
+};
+
 struct ProfScope {
     Ctx* c;
     int id;
@@ -269,6 +306,21 @@ static void prof_drain(Ctx* c)
 }
 
 static int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// What the kernels that read and write whole dwords rely on (k_pyramid.hip stage 1 / copy_out, the tracker's tile loader,
+// the corner kernels' staging): every level starts on a 256-B boundary, its row pitch is a multiple of 64 B >= the width
+// rounded up to 4, so an aligned dword that STARTS inside a row (x = 0 mod 4, x < w) ends inside that row's pitch; and
+// the allocation ends >= 256 B behind the last level, so a dword read that starts inside the last row of the last level
+// stays inside the allocation.  Checked for every geometry a handle lays out (icelk_create, begin_frame).
+static bool layout_ok(const Slot& s)
+{
+    for (int l = 0; l < kMaxLevels; l++) {
+        const Level& L = s.lv[l];
+        if (((uintptr_t)L.ptr & 255u) || (L.pitch % kPitchAlign) || L.pitch < ((L.w + 3) & ~3)) return false;
+        if (L.ptr + (size_t)L.pitch * L.h + 256 > s.base + s.bytes) return false;
+    }
+    return true;
+}
 
 // level geometry of a w x h frame inside a slot allocation
 static void layout_levels(Slot& s, int w, int h)
@@ -371,6 +423,7 @@ static int begin_frame(Ctx* c, int slot, int w, int h)
     s.w = w;
     s.h = h;
     layout_levels(s, w, h);
+    if (!layout_ok(s)) FAIL(c, ICELK_ECAP, "slot layout violates the dword-access invariant (internal)");
     s.levels_built = 0;
     s.gen++;
     return ICELK_OK;
@@ -811,6 +864,7 @@ static void activate_eig_out(Ctx* c, int idx)
 // generation, blockSize and mask still match.
 static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
 {
+    Range rg("icelk detect_prepare (corner candidates ahead)");
     int rc = check_slot(c, slot, true);
     if (rc) return rc;
     if (!fused_block_size(block_size) || getenv("ICELK_GENERIC_CORNERS") || c->corner_variant) return ICELK_OK;
@@ -872,6 +926,7 @@ static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
 static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double quality, double min_distance,
                         int block_size)
 {
+    Range rg("icelk detect_begin (candidates + min-distance stage)");
     int rc = check_slot(c, slot, true);
     if (rc) return rc;
     if (!(quality > 0) || min_distance < 0 || block_size <= 0) FAIL(c, ICELK_EARG, "bad detector parameters");
@@ -969,6 +1024,7 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
 
 static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
 {
+    Range rg("icelk detect_finish (host round trip, sort, corner list)");
     {
         const int k = det_oldest(c);
         if (k < 0) FAIL(c, ICELK_ESTATE, "no detection in flight");
@@ -1161,6 +1217,7 @@ static bool same_lk_params(const LKParams& a, const LKParams& b)
 static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int win_h, int max_level, int crit_type,
                           int max_count, double epsilon, double min_eig_threshold, float fb_threshold, bool defer)
 {
+    Range rg(defer ? "icelk seg_track_defer" : "icelk seg_track (fused forward+backward LK launch)");
     int rc = check_slot(c, slot_prev, true);
     if (!rc) rc = check_slot(c, slot_next, true);
     if (rc) return rc;
@@ -1352,6 +1409,11 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
             return fail(ICELK_EHIP);
         }
         s.used = s.used_own;
+        layout_levels(s, max_w, max_h);
+        if (!layout_ok(s)) {
+            c->err = "slot layout violates the dword-access invariant (internal)";
+            return fail(ICELK_ECAP);
+        }
     }
     for (auto& S : c->sb) {
         if (hipEventCreateWithFlags(&S.used_own, hipEventDisableTiming) != hipSuccess) {
@@ -1566,6 +1628,7 @@ int icelk_upload_gray_async(icelk_t* h, int slot, const uint8_t* pinned_host, in
 {
     if (!h) return ICELK_EARG;
     Ctx* c = C(h);
+    Range rg("icelk upload_gray_async");
     if (!pinned_host || stride < w) FAIL(c, ICELK_EARG, "bad host image");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = begin_frame(c, slot, w, h_);
@@ -1740,6 +1803,7 @@ int icelk_build_pyramid_ahead(icelk_t* h, int slot, int win_w, int win_h, int ma
 {
     if (!h) return ICELK_EARG;
     Ctx* c = C(h);
+    Range rg("icelk build_pyramid_ahead");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = check_slot(c, slot, true);
     if (rc) return rc;

@@ -497,3 +497,28 @@ def test_named_variants_equal_the_oracles(orc, synth, name, value):
             assert np.array_equal(c.min_eig_map(0, 10).view(np.uint32), base_map.view(np.uint32))
     finally:
         c.close()
+
+
+def test_pyramid_of_forty_random_sizes(orc):
+    """The one-launch pyramid reads and writes whole dwords and mirrors level borders inside LDS; what keeps that inside every
+    allocation and every region is a property of the slot layout (icelk_abi.hip layout_ok) and of the tile geometry -- not
+    of the sizes the other tests happen to use.  Forty random frames from 1 x 1 to 300 x 300 (levels narrower than a halo,
+    than a dword, than the filter), both geometries, every level against the oracle.  (Round 2 lost a run to a GPU abort
+    in a work-in-progress form of this kernel on the 64 x 48 case -- levels narrower than a halo; that form never reached
+    the history.)"""
+    from iceberg_tracking_code_amd import Context
+    rng = np.random.RandomState(2026)
+    sizes = [(1, 1), (2, 2), (3, 1), (1, 5), (4, 4), (5, 300), (300, 5), (64, 48), (65, 129), (128, 128), (129, 127)]
+    sizes += [(int(rng.randint(1, 301)), int(rng.randint(1, 301))) for _ in range(29)]
+    c = Context(300, 300, n_slots=1, max_pts=64)
+    for w, h in sizes:
+        img = rng.randint(0, 256, size=(h, w)).astype(np.uint8)
+        ref = orc.build_pyramid(img, (3, 3), 8)
+        for ahead in (False, True):
+            c.upload_gray(0, img)
+            if ahead:
+                c.build_pyramid_ahead(0, (3, 3), 8)
+            assert c.build_pyramid(0, (3, 3), 8) == len(ref) - 1, (w, h)
+            for l, r in enumerate(ref):
+                assert np.array_equal(c.download_level(0, l), r), (w, h, ahead, l)
+    c.close()
