@@ -57,7 +57,10 @@ struct Geo {
     static constexpr int L1_OX = -8, L1_OY = -6, L1_W = T0 / 2 + 12, L1_H = T0 / 2 + 9;   // needs [-6,T0/2+2]: columns 2.. of the region
     static constexpr int L2_OX = -4, L2_OY = -2, L2_W = T0 / 4 + 8, L2_H = T0 / 4 + 3;    // needs [-2,T0/4]: columns 2.. of the region
     static constexpr int L3_W = T0 / 8, L3_H = T0 / 8;
-    static constexpr int L0_BYTES = L0_W * L0_H, L1_BYTES = L1_W * L1_H, L2_BYTES = L2_W * L2_H, L3_BYTES = L3_W * L3_H;
+    // LDS row pitch of the level-0 region: a multiple of 16 B, so that a tile inside the frame is fetched and stored as
+    // 16-byte pieces (global_load_dwordx4 -> ds_write_b128: a quarter of the load and store instructions)
+    static constexpr int L0_P = (L0_W + 15) & ~15;
+    static constexpr int L0_BYTES = L0_P * L0_H, L1_BYTES = L1_W * L1_H, L2_BYTES = L2_W * L2_H, L3_BYTES = L3_W * L3_H;
     static constexpr int LDS_BYTES = ((L0_BYTES + 15) & ~15) + ((L1_BYTES + 15) & ~15) + ((L2_BYTES + 15) & ~15) + ((L3_BYTES + 15) & ~15);
 };
 
@@ -98,16 +101,17 @@ __device__ __forceinline__ void pyr_task(const uint8_t* __restrict__ src, int sp
 // One level of the tile: NCOL x ROWS outputs of the destination region (columns from column FIRST_COL of the region),
 // runs of CH rows per task; the ROWS % CH rows left over are tasks of their own (a run of CH with one live row would
 // cost as much as a full one).  Region index (ox, oy) <-> source region: column 2*ox + scol, row 2*oy.
-template <int NT, int CH, int NCOL, int ROWS, int FIRST_COL>
+// CH0 .. CH1-1 = the runs of CH rows this call forms (all of them by default); the leftover rows go with the last run
+template <int NT, int CH, int NCOL, int ROWS, int FIRST_COL, int CH0 = 0, int CH1 = ROWS / CH>
 __device__ __forceinline__ void pyr_level(const uint8_t* __restrict__ src, int spitch, int scol, uint8_t* __restrict__ dst,
                                           int dpitch, int tid)
 {
     constexpr int NFULL = ROWS / CH, REM = ROWS - NFULL * CH;
-    for (int t = tid; t < NCOL * NFULL; t += NT) {
-        const int ch = t / NCOL;
-        pyr_task<CH>(src, spitch, scol, dst, dpitch, FIRST_COL + (t - ch * NCOL), ch * CH);
+    for (int t = tid; t < NCOL * (CH1 - CH0); t += NT) {
+        const int ch = CH0 + t / NCOL;
+        pyr_task<CH>(src, spitch, scol, dst, dpitch, FIRST_COL + (t - (ch - CH0) * NCOL), ch * CH);
     }
-    if constexpr (REM > 0) {
+    if constexpr (REM > 0 && CH1 == NFULL) {
         // the leftover rows: threads from the far end of the workgroup, so that they fall into the partly filled last
         // round of the loop above rather than into a round of their own
         for (int t = NT - 1 - tid; t < NCOL; t += NT) pyr_task<REM>(src, spitch, scol, dst, dpitch, FIRST_COL + t, NFULL * CH);
@@ -158,6 +162,7 @@ __global__ __launch_bounds__(NT) void k_pyramid(LevelIO S, LevelIO D1, LevelIO D
 #define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[8 * (blockIdx.y * gridDim.x + blockIdx.x) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     STAMP(0);
     using G = Geo<T0, NT>;
+    constexpr int L0_P = G::L0_P;
     constexpr int L0_OX = G::L0_OX, L0_OY = G::L0_OY, L0_W = G::L0_W, L0_H = G::L0_H, L1_OX = G::L1_OX, L1_OY = G::L1_OY,
                   L1_W = G::L1_W, L1_H = G::L1_H, L2_OX = G::L2_OX, L2_OY = G::L2_OY, L2_W = G::L2_W, L2_H = G::L2_H,
                   L3_W = G::L3_W, L3_H = G::L3_H;
@@ -178,7 +183,30 @@ __global__ __launch_bounds__(NT) void k_pyramid(LevelIO S, LevelIO D1, LevelIO D
     // 4-aligned, so no dword straddles the LEFT edge, and one that straddles the right edge reads into the row padding
     // (pitch is a multiple of 64), bytes the edge fill below overwrites or nothing ever looks at.  No byte path, no
     // branch: every load of the thread is in flight before the first LDS write waits for one.
-    {
+    if (interior) {
+        // 16 bytes per load and per LDS store; the last piece of a row runs up to 12 B past the region: inside the frame's
+        // row pitch (the region ends inside the frame, the pitch is a multiple of 64), and bytes nothing reads
+        constexpr int NQ = L0_P / 16, N = (NQ * L0_H + NT - 1) / NT;
+        uint4 v[N];
+        const uint8_t* base = S.ptr + (size_t)(y0 + L0_OY) * S.pitch + (x0 + L0_OX);
+#pragma unroll
+        for (int m = 0; m < N; m++) {
+            int i = tid + NT * m;
+            i = i < NQ * L0_H ? i : NQ * L0_H - 1;      // surplus threads of the last round fetch the last piece again
+            const int r = i / NQ, c = i - r * NQ;
+            v[m] = *reinterpret_cast<const uint4*>(base + (size_t)r * S.pitch + 16 * c);
+        }
+#pragma unroll
+        for (int m = 0; m < N; m++) {
+            int i = tid + NT * m;
+            i = i < NQ * L0_H ? i : NQ * L0_H - 1;
+            reinterpret_cast<uint4*>(R0)[i] = v[m];
+        }
+        // (Committing the first two thirds of the rounds, forming the level-1 runs that read nothing below them, then the
+        // rest -- so that the last loads are still in flight during the first runs -- was measured and is slower: 12.1 ->
+        // 13.1 us, 18.8 -> 22.0 us for the one-wave geometry; the extra barrier and the extra partly filled round of tasks
+        // cost more than the overlap returns.)
+    } else {
         constexpr int NDW = L0_W / 4, N = (NDW * L0_H + NT - 1) / NT;
         uint32_t v[N];
         const int gx0 = x0 + L0_OX, gy0 = y0 + L0_OY;
@@ -194,16 +222,16 @@ __global__ __launch_bounds__(NT) void k_pyramid(LevelIO S, LevelIO D1, LevelIO D
 #pragma unroll
         for (int m = 0; m < N; m++) {
             const int i = tid + NT * m;
-            if (i < NDW * L0_H) reinterpret_cast<uint32_t*>(R0)[i] = v[m];
+            const int r = i / NDW, c = i - r * NDW;
+            if (i < NDW * L0_H) reinterpret_cast<uint32_t*>(R0 + r * L0_P)[c] = v[m];
         }
     }
-    __syncthreads();
-    if (!interior) fill_edges<NT>(R0, L0_W, L0_W, L0_H, x0 + L0_OX, y0 + L0_OY, S.w, S.h, tid);
-    STAMP(1);
-
     // ---- stages 2-4: level 1 (region columns 2 .. W-2, every row), level 2 (columns 2 .. T0/4+4), level 3 ----
     // region index (ox, oy) of a level <-> source region: column 2*ox + scol, row 2*oy, with scol = +2, -2, +2
-    pyr_level<NT, 8, L1_W - 3, L1_H, 2>(R0, L0_W, 2, R1, L1_W, tid);
+    __syncthreads();
+    if (!interior) fill_edges<NT>(R0, L0_P, L0_W, L0_H, x0 + L0_OX, y0 + L0_OY, S.w, S.h, tid);
+    STAMP(1);
+    pyr_level<NT, 8, L1_W - 3, L1_H, 2>(R0, L0_P, 2, R1, L1_W, tid);
     __syncthreads();
     STAMP(2);
     copy_out<NT>(R1, L1_W, -L1_OX, -L1_OY, T0 / 2, T0 / 8, D1, x1, y1, tid);
