@@ -7,7 +7,7 @@
 There is no CPU fallback: calls raise if libicelk.so has not been built or no GPU is present.
 """
 from .api import (COLOR_BGR2GRAY, COLOR_RGB2GRAY, calcOpticalFlowPyrLK, cvtColor, default_context,  # noqa: F401
-                  goodFeaturesToTrack, release, set_device, set_gray_variant)
+                  goodFeaturesToTrack, release, set_device, set_gray_variant, set_variant)
 from .context import (Context, DEFAULT_CRITERIA, GRAY_CV3, GRAY_CV4, OPTFLOW_LK_GET_MIN_EIGENVALS,  # noqa: F401
                       OPTFLOW_USE_INITIAL_FLOW, TERM_CRITERIA_COUNT, TERM_CRITERIA_EPS, TERM_CRITERIA_MAX_ITER)
 from .tracker import (REF_FB_THRESHOLD, REF_FEATURE_PARAMS, REF_LK_PARAMS, SegmentTracker,  # noqa: F401

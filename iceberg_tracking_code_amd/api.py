@@ -17,7 +17,7 @@ from .context import (Context, DEFAULT_CRITERIA, GRAY_CV3, GRAY_CV4, OPTFLOW_LK_
 COLOR_BGR2GRAY = 6
 COLOR_RGB2GRAY = 7
 
-_default = {"ctx": None, "gray_variant": GRAY_CV4, "device": 0}
+_default = {"ctx": None, "gray_variant": GRAY_CV4, "device": 0, "variants": {}}
 
 
 def set_gray_variant(variant):
@@ -26,6 +26,17 @@ def set_gray_variant(variant):
     if variant not in (GRAY_CV3, GRAY_CV4):
         raise ValueError("variant must be 3 or 4")
     _default["gray_variant"] = variant
+
+
+def set_variant(name, value):
+    """A named build-dependent variant of OpenCV's arithmetic for the cv2-shaped calls of this module: "lk_sums" 0 | 1 | 2
+    (exact / OpenCV 3.x SSE2 / 4.x CV_SIMD128 summation order of the LK sums), "sobel_fma" 0..3, "eig_fma" 0 | 1
+    (icelk_set_variant; DESIGN.md section 2 has how far apart they are).  0 = default."""
+    if name not in ("lk_sums", "sobel_fma", "eig_fma"):
+        raise ValueError("unknown variant %r" % (name,))
+    _default["variants"][name] = int(value)
+    if _default["ctx"] is not None:
+        _default["ctx"].set_variant(name, value)
 
 
 def set_device(device):
@@ -46,6 +57,8 @@ def default_context(w, h, n_pts=0):
         if ctx is not None:
             ctx.close()
         ctx = Context(mw, mh, n_slots=2, max_pts=mp, device=_default["device"])
+        for name, value in _default["variants"].items():
+            ctx.set_variant(name, value)
         _default["ctx"] = ctx
     return ctx
 

@@ -244,3 +244,35 @@ def test_box_sums_of_the_covariance_planes_are_exact_in_double():
                 direct += v
             sliding = float(np.cumsum(plane.astype(np.float64))[bs * bs - 1])
             assert direct == math.fsum(win.tolist()) == sliding
+
+
+def test_named_variants_are_live_close_and_reset(orc, synth):
+    """orc_set_variant (every build-dependent OpenCV semantic a named switch): each variant changes
+    something, stays within the distance tools/oracle_variants.py reports at full size (LK sums: far below north_star's
+    1e-3 px here; fused Sobel / eigenvalue arithmetic: <= 64 ulp of the map, same corner set), and the context manager
+    puts every switch back to its default."""
+    img0 = synth.frame(320, 240, 0, 0, 5)
+    img1 = synth.frame(320, 240, 300, -170, 5)
+    pts = orc.good_features(img0, 400, 0.01, 6, None, 5).reshape(-1, 2)
+    base = orc.track_fb(img0, img1, pts, (21, 21), 3, (3, 30, 0.01))
+    for mode in (1, 2):
+        with orc.variants(lk_sums=mode):
+            assert orc.get_variant("lk_sums") == mode
+            v = orc.track_fb(img0, img1, pts, (21, 21), 3, (3, 30, 0.01))
+        assert orc.get_variant("lk_sums") == 0
+        d = np.abs(v["p1"] - base["p1"]).max(axis=1)
+        assert 0 < (d > 0).sum() and d.max() < 1e-3
+        assert np.array_equal(v["st_fwd"], base["st_fwd"]) and np.array_equal(v["valid"], base["valid"])
+    e0 = orc.min_eig_map(img0, 10)
+    c0 = orc.good_features(img0, 0, 0.01, 6, None, 10)
+    for kw in (dict(sobel_fma=1), dict(sobel_fma=2), dict(sobel_fma=3), dict(eig_fma=1)):
+        with orc.variants(**kw):
+            e = orc.min_eig_map(img0, 10)
+            c = orc.good_features(img0, 0, 0.01, 6, None, 10)
+        ulp = np.abs(e.view(np.int32).astype(np.int64) - e0.view(np.int32).astype(np.int64))
+        assert 0 < (ulp > 0).sum() and ulp.max() <= 64, kw
+        assert {tuple(p) for p in c.reshape(-1, 2)} == {tuple(p) for p in c0.reshape(-1, 2)}, kw
+    assert all(orc.get_variant(k) == 0 for k in orc.VARIANTS)
+    assert np.array_equal(orc.min_eig_map(img0, 10).view(np.uint32), e0.view(np.uint32))
+    with pytest.raises(ValueError):
+        orc.set_variant("lk_sums", 7)
