@@ -369,6 +369,234 @@ __global__ __launch_bounds__(256) void k_eig_nms(const uint8_t* __restrict__ img
     if (tid == 0) blk_count[bid] = s_list_n;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K6+K7 in STRIPS (round 3; the default for blockSize 3/5/7/10).  k_eig_nms pays for its 64x16 tile twice: the Sobel stage
+// runs on 27x75 positions and the row sums on 27x66 for 16x64 outputs (1.98x / 1.74x), and its column pass and eigenvalue
+// stage occupy 198 of 256 threads.  Here a workgroup walks DOWN a strip 245 outputs wide (blockSize 10) and 62 high:
+//   * one thread per covariance column.  The Sobel pair rolls down the column in registers (row difference and row
+//     smooth of the two pixel rows above are kept; three byte loads per new row, issued one row ahead; BORDER_REFLECT_101
+//     in x costs nothing: the three column offsets of a thread are fixed).  The COLUMN sums come first: a running double
+//     sum per plane, + the new product, - the one blockSize rows up, kept as f32 in a register ring (static indices: the
+//     row loop is unrolled by lcm(blockSize, 4)).  All of these sums are exact (window_sums' note), so summing columns
+//     first and sliding the window give bit for bit the value of OpenCV's row-then-column running sums.
+//   * every 4 rows: the column sums of the 4 rows (LDS, 24 KB) -> row sums by threads that own 4 consecutive outputs of
+//     one row (sliding window, 15 additions per plane) -> min eigenvalue -> an 8-row ring of the eigenvalue map (LDS);
+//     then the 3x3 non-max test, one thread per column, for the 4 rows whose lower neighbour now exists.
+// Strips that touch the top or bottom of the image (FRESH) reflect rows: the covariance row at a reflected position is
+// the one AT that position with its own neighbours, so the roll does not apply there and each row loads its 3x3 afresh.
+// Halo: 1.045 in x, 73 covariance rows for 62 output rows.  Regions: 4 per workgroup (16 output rows each).
+// ------------------------------------------------------------------------------------------------
+constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
+
+template <int BS>
+struct StripCfg {
+    static constexpr int NT = 256;                 // threads = covariance columns
+    static constexpr int AN = BS / 2;
+    static constexpr int EW = NT - (BS - 1);       // eigenvalue columns
+    static constexpr int TW = EW - 2;              // output columns
+    static constexpr int R = 4;                    // rows per batch = waves
+    static constexpr int UNROLL = BS * R / gcd_c(BS, R);   // rows per trip of the row loop: ring slots and batch rows static
+    // eigenvalue rows: whole trips -- an exit from inside the unrolled trip would meet the register ring in a different
+    // rotation at every batch (measured: 230 VGPRs instead of 146)
+    static constexpr int EH = (64 / UNROLL) * UNROLL;
+    static constexpr int SH = EH - 2;              // output rows
+    static constexpr int NROWS = EH + BS - 1;      // covariance rows walked
+    static constexpr int RX = 4;                   // outputs per row task
+    static constexpr int NG = (EW + RX - 1) / RX;  // row tasks per row
+    static constexpr int VP = NT + 2;              // doubles per row of column sums (the last task reads 2 beyond)
+    static constexpr int SUB = 16, NSUB = (SH + SUB - 1) / SUB;
+    static constexpr int V_BYTES = R * 3 * VP * 8;
+    static constexpr int E_BYTES = 8 * NT * 4;
+    static constexpr int LDS_BYTES = V_BYTES + E_BYTES;
+    static_assert(EH % R == 0 && NG <= 64 && RX * NG <= NT, "one wave per row of a batch");
+    static_assert(RX * (NG - 1) + RX + BS - 2 < VP, "row tasks stay inside a row of column sums");
+    static_assert((VP * 8) % 16 == 0, "16-byte reads of the column sums");
+};
+
+struct SobelRoll {
+    float d1, d2, t1, t2;   // row difference / row smooth of pixel rows yc (1) and yc - 1 (2)
+};
+
+__device__ __forceinline__ float smooth3(float a, float b, float c, float k0, float k1)
+{
+    return __fadd_rn(__fadd_rn(__fmul_rn(k1, a), __fmul_rn(k0, b)), __fmul_rn(k1, c));
+}
+
+template <int BS, bool FRESH>
+__device__ __forceinline__ void strip_body(const uint8_t* __restrict__ img, int w, int h, int pitch, float k0, float k1,
+                                           const uint8_t* __restrict__ mask, int mask_pitch, unsigned* __restrict__ max_key,
+                                           unsigned long long* __restrict__ raw, int* __restrict__ blk_count,
+                                           float* __restrict__ eig_out, uint8_t* smem, int* s_cnt)
+{
+    using C = StripCfg<BS>;
+    double* Vb = reinterpret_cast<double*>(smem);                 // [R][3][VP]
+    float* Er = reinterpret_cast<float*>(smem + C::V_BYTES);      // [8][NT]
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * C::TW, y0 = blockIdx.y * C::SH;
+    const int xs = x0 - 1 - C::AN, ys = y0 - 1 - C::AN;           // image position of covariance column / row 0
+    const int rx = reflect101(xs + tid, w);
+    const int xm = reflect101(rx - 1, w), xp = reflect101(rx + 1, w);
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (tid < C::NSUB) s_cnt[tid] = 0;
+
+    float ring[3][BS];
+#pragma unroll
+    for (int k = 0; k < BS; k++) ring[0][k] = ring[1][k] = ring[2][k] = 0.f;
+    double V[3] = {0.0, 0.0, 0.0};
+    SobelRoll S{};
+    unsigned pa = 0, pb = 0, pc = 0;   // the pixel row one ahead of the roll
+    if (!FRESH) {
+        const uint8_t* r2 = img + (size_t)(ys - 1) * pitch;
+        const uint8_t* r1 = r2 + pitch;
+        const uint8_t* r0 = r1 + pitch;
+        const float a2 = (float)r2[xm], b2 = (float)r2[rx], c2 = (float)r2[xp];
+        const float a1 = (float)r1[xm], b1 = (float)r1[rx], c1 = (float)r1[xp];
+        S.d2 = __fsub_rn(c2, a2); S.t2 = smooth3(a2, b2, c2, k0, k1);
+        S.d1 = __fsub_rn(c1, a1); S.t1 = smooth3(a1, b1, c1, k0, k1);
+        pa = r0[xm]; pb = r0[rx]; pc = r0[xp];
+    }
+    // products of covariance row r (image row ys + r)
+    auto cov_row = [&](int r, float& xx, float& xy, float& yy) {
+        float dtop, dmid, dbot, ttop, tbot;
+        if (FRESH) {
+            const int ry = reflect101(ys + r, h);
+            const uint8_t* q0 = img + (size_t)reflect101(ry - 1, h) * pitch;
+            const uint8_t* q1 = img + (size_t)ry * pitch;
+            const uint8_t* q2 = img + (size_t)reflect101(ry + 1, h) * pitch;
+            const float a0 = (float)q0[xm], b0 = (float)q0[rx], c0 = (float)q0[xp];
+            const float a1 = (float)q1[xm], c1 = (float)q1[xp];
+            const float a2 = (float)q2[xm], b2 = (float)q2[rx], c2 = (float)q2[xp];
+            dtop = __fsub_rn(c0, a0); dmid = __fsub_rn(c1, a1); dbot = __fsub_rn(c2, a2);
+            ttop = smooth3(a0, b0, c0, k0, k1); tbot = smooth3(a2, b2, c2, k0, k1);
+        } else {
+            const float a = (float)pa, b = (float)pb, c = (float)pc;
+            int nr = ys + r + 2;                  // next pixel row; past the last row needed it is only kept inside the image
+            nr = nr < h ? nr : h - 1;
+            const uint8_t* q = img + (size_t)nr * pitch;
+            pa = q[xm]; pb = q[rx]; pc = q[xp];
+            dtop = S.d2; dmid = S.d1; dbot = __fsub_rn(c, a);
+            ttop = S.t2; tbot = smooth3(a, b, c, k0, k1);
+            S.d2 = S.d1; S.d1 = dbot; S.t2 = S.t1; S.t1 = tbot;
+        }
+        const float dx = __fadd_rn(__fmul_rn(__fadd_rn(dtop, dbot), k1), __fmul_rn(dmid, k0));
+        const float dy = __fsub_rn(tbot, ttop);
+        xx = __fmul_rn(dx, dx); xy = __fmul_rn(dx, dy); yy = __fmul_rn(dy, dy);
+    };
+
+    // the first blockSize - 1 covariance rows only fill the window
+#pragma unroll
+    for (int r = 0; r < BS - 1; r++) {
+        float p[3];
+        cov_row(r, p[0], p[1], p[2]);
+#pragma unroll
+        for (int q = 0; q < 3; q++) { V[q] += (double)p[q]; ring[q][r] = p[q]; }
+    }
+
+    unsigned best = 0;
+    const int wr = tid >> 6, g = tid & 63;
+    for (int base = 0; base < C::EH; base += C::UNROLL) {
+#pragma unroll
+        for (int j = 0; j < C::UNROLL; j++) {
+            const int i = base + j;                   // eigenvalue row this covariance row completes
+            const int K = (BS - 1 + j) % BS;          // ring slot: holds the product blockSize rows up
+            float p[3];
+            cov_row(BS - 1 + i, p[0], p[1], p[2]);
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                V[q] = (V[q] + (double)p[q]) - (double)ring[q][K];
+                ring[q][K] = p[q];
+                Vb[((j % C::R) * 3 + q) * C::VP + tid] = V[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);           // rows stay in order: the loads of 20 unrolled rows are not hoisted
+            if (j % C::R != C::R - 1) continue;
+            const int eb = i / C::R;                  // batch: eigenvalue rows eb*R .. eb*R + R-1
+            __syncthreads();
+            if (g < C::NG) {
+                double Sm[3][C::RX];
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    double v[C::RX + BS - 1];
+                    const double* src = Vb + (wr * 3 + q) * C::VP + C::RX * g;
+#pragma unroll
+                    for (int k = 0; k < C::RX + BS - 1; k++) v[k] = src[k];
+                    window_sums<C::RX, BS>(v, Sm[q]);
+                    __builtin_amdgcn_sched_barrier(0);   // one plane's 13 doubles at a time, not all three
+                }
+                const int er = eb * C::R + wr;
+                float e[C::RX];
+#pragma unroll
+                for (int k = 0; k < C::RX; k++) e[k] = min_eig_of(Sm[0][k], Sm[1][k], Sm[2][k]);
+                *reinterpret_cast<float4*>(Er + (er & 7) * C::NT + C::RX * g) = make_float4(e[0], e[1], e[2], e[3]);
+                const int y = y0 - 1 + er;
+                if (er >= 1 && er <= C::SH && y < h) {
+#pragma unroll
+                    for (int k = 0; k < C::RX; k++) {
+                        const int ce = C::RX * g + k, x = x0 - 1 + ce;
+                        if (ce >= 1 && ce <= C::TW && x < w) {
+                            if (eig_out) eig_out[(size_t)y * w + x] = e[k];
+                            if (!mask || mask[(size_t)y * mask_pitch + x]) {
+                                const unsigned key = ordered_key(e[k]);
+                                best = key > best ? key : best;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            {
+                // 3x3 non-max test of eigenvalue rows eb*R - 1 .. eb*R + 2, column tid
+                const int x = x0 - 1 + tid;
+                if (tid >= 1 && tid <= C::TW && x >= 1 && x < w - 1) {
+                    float m3[6], mid[6], side[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const float* row = Er + ((eb * C::R - 2 + k) & 7) * C::NT + tid;
+                        const float l = row[-1], c = row[0], r = row[1];
+                        mid[k] = c;
+                        side[k] = fmaxf(l, r);
+                        m3[k] = fmaxf(side[k], c);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int c = eb * C::R - 1 + q, y = y0 - 1 + c;
+                        if (c < 1 || c > C::SH || y < 1 || y >= h - 1) continue;
+                        const float v = mid[q + 1];
+                        if (!(v > 0.f)) continue;
+                        const float m = fmaxf(fmaxf(m3[q], m3[q + 2]), side[q + 1]);
+                        if (v < m) continue;
+                        if (mask && !mask[(size_t)y * mask_pitch + x]) continue;
+                        const int sub = (c - 1) / C::SUB;
+                        const int pos = atomicAdd(&s_cnt[sub], 1);
+                        raw[((size_t)bid * C::NSUB + sub) * (C::TW * C::SUB) + pos] =
+                            ((unsigned long long)ordered_key(v) << 32) | pack_xy(x, y);
+                    }
+                }
+            }
+        }
+    }
+    publish_max(max_key, best, tid);
+    __syncthreads();
+    if (tid < C::NSUB) blk_count[bid * C::NSUB + tid] = s_cnt[tid];
+}
+
+template <int BS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_eig_strip(const uint8_t* __restrict__ img, int w, int h, int pitch, float k0,
+                                                    float k1, const uint8_t* __restrict__ mask, int mask_pitch,
+                                                    unsigned* __restrict__ max_key,
+                                                    unsigned long long* __restrict__ raw, int* __restrict__ blk_count,
+                                                    float* __restrict__ eig_out)
+{
+    using C = StripCfg<BS>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int s_cnt[C::NSUB];
+    const int ys = (int)blockIdx.y * C::SH - 1 - C::AN;
+    // pixel rows ys - 1 .. ys + NROWS are read by the rolling form
+    if (ys - 1 >= 0 && ys + C::NROWS <= h - 1)
+        strip_body<BS, false>(img, w, h, pitch, k0, k1, mask, mask_pitch, max_key, raw, blk_count, eig_out, smem, s_cnt);
+    else
+        strip_body<BS, true>(img, w, h, pitch, k0, k1, mask, mask_pitch, max_key, raw, blk_count, eig_out, smem, s_cnt);
+}
+
 // workgroup-aggregated append: every thread offers at most one key per call; one global atomic per call
 __device__ __forceinline__ void block_append(bool keep, unsigned long long key, unsigned long long* out,
                                              int* out_count, int* s_cnt, int* s_base)
@@ -835,6 +1063,43 @@ void launch_fused(hipStream_t s, const Level& img, float k0, float k1, const uin
     src->region = C::TW * C::TH;
 }
 
+template <int BS>
+void launch_strip(hipStream_t s, const Level& img, float k0, float k1, const uint8_t* mask, int mask_pitch,
+                  unsigned* max_key, unsigned long long* raw, int* blk_count, float* eig_out, CandSrc* src)
+{
+    using C = StripCfg<BS>;
+    dim3 grid((img.w + C::TW - 1) / C::TW, (img.h + C::SH - 1) / C::SH);
+    hipLaunchKernelGGL((k_eig_strip<BS>), grid, dim3(C::NT), C::LDS_BYTES, s, img.ptr, img.w, img.h, img.pitch, k0, k1, mask,
+                       mask_pitch, max_key, raw, blk_count, eig_out);
+    src->keys = raw;
+    src->blk_count = blk_count;
+    src->nblk = (int)(grid.x * grid.y) * C::NSUB;
+    src->region = C::TW * C::SUB;
+}
+
+// regions / keys the strip layout needs, whichever blockSize is asked for later
+template <int BS>
+void strip_geometry(int w, int h, size_t* regions, size_t* keys)
+{
+    using C = StripCfg<BS>;
+    const size_t r = (size_t)((w + C::TW - 1) / C::TW) * ((h + C::SH - 1) / C::SH) * C::NSUB;
+    const size_t k = r * (size_t)(C::TW * C::SUB);
+    *regions = r > *regions ? r : *regions;
+    *keys = k > *keys ? k : *keys;
+}
+size_t strip_regions(int w, int h)
+{
+    size_t r = 0, k = 0;
+    strip_geometry<3>(w, h, &r, &k); strip_geometry<5>(w, h, &r, &k); strip_geometry<7>(w, h, &r, &k); strip_geometry<10>(w, h, &r, &k);
+    return r;
+}
+size_t strip_keys(int w, int h)
+{
+    size_t r = 0, k = 0;
+    strip_geometry<3>(w, h, &r, &k); strip_geometry<5>(w, h, &r, &k); strip_geometry<7>(w, h, &r, &k); strip_geometry<10>(w, h, &r, &k);
+    return k;
+}
+
 }  // namespace
 
 size_t min_eig_lds_bytes(int block_size)
@@ -850,14 +1115,16 @@ size_t candidate_capacity(int w, int h)
 {
     const size_t fused = (size_t)((w + 63) / 64) * ((h + 15) / 16) * (64 * 16);
     const size_t generic = (size_t)((w + 255) / 256) * ((h + NMS_ROWS - 1) / NMS_ROWS) * (256 * NMS_ROWS);
-    const size_t fast = fast_key_capacity(w, h);
-    const size_t m = fused > generic ? fused : generic;
-    return (m > fast ? m : fast) + 1024;
+    const size_t fast = fast_key_capacity(w, h), strip = strip_keys(w, h);
+    size_t m = fused > generic ? fused : generic;
+    m = m > fast ? m : fast;
+    return (m > strip ? m : strip) + 1024;
 }
 size_t candidate_blocks(int w, int h)
 {
-    const size_t a = (size_t)((w + 63) / 64) * ((h + 15) / 16), b = fast_regions(w, h);
-    return (a > b ? a : b) + 16;
+    const size_t a = (size_t)((w + 63) / 64) * ((h + 15) / 16), b = fast_regions(w, h), c = strip_regions(w, h);
+    const size_t m = a > b ? a : b;
+    return (m > c ? m : c) + 16;
 }
 
 // K6 alone, writing the map with the any-blockSize kernel.
@@ -913,7 +1180,18 @@ void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int bl
     if (two_pass && !use_generic && fused_block_size(block_size) && !eig_out_or_null &&
         launch_candidates_fast(s, D, img, block_size, mask, mask_pitch, quality))
         return;
-    if (!use_generic && fused_block_size(block_size)) {
+    // ICELK_TILE_CORNERS=1: round 2's 64x16-tile kernel instead of the strip kernel (same lists; kept for comparison)
+    const bool tiles = getenv("ICELK_TILE_CORNERS") != nullptr;
+    if (!use_generic && fused_block_size(block_size) && !tiles) {
+        float k0, k1;
+        sobel_scale(block_size, &k0, &k1);
+        switch (block_size) {
+            case 3: launch_strip<3>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
+            case 5: launch_strip<5>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
+            case 7: launch_strip<7>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
+            default: launch_strip<10>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
+        }
+    } else if (!use_generic && fused_block_size(block_size)) {
         float k0, k1;
         sobel_scale(block_size, &k0, &k1);
         switch (block_size) {
