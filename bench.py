@@ -659,12 +659,12 @@ def main():
                                                "class_cost_source": mixes.get("class_cost_source")}
                     out["roofline"]["valu_issue"] = vio
                     bes = pj.get("beside_valu_insts_per_launch")
-                    if bes and bes.get("k_eig_nms") and trk_mix and cname in ("c2", "c3", "c4") and lkp["pairs_per_launch"] > 1.5:
+                    if bes and (bes.get("corner_kernel") or bes.get("k_eig_nms")) and trk_mix and cname in ("c2", "c3", "c4") and lkp["pairs_per_launch"] > 1.5:
                         # everything the SIMDs issue per period of the pipeline (two frames: one joint tracker launch, one
                         # corner kernel, two pyramids, one min-distance chain), each kernel priced with its own mix, against
                         # the wall time of that period
                         ns = lambda key: ((mixes.get(key) or trk_mix)["ns_per_valu_inst"])   # noqa: E731
-                        parts = {"tracker": (vi, ns("tracker")), "corner_kernel": (bes["k_eig_nms"], ns("corner_kernel")),
+                        parts = {"tracker": (vi, ns("tracker")), "corner_kernel": (bes.get("corner_kernel") or bes.get("k_eig_nms"), ns("corner_kernel")),
                                  "pyramids": (2 * (bes.get("k_pyramid_ahead") or 0), ns("pyramid_one_wave")),
                                  "min_distance_chain": (bes.get("min_distance_chain") or 0, ns("tracker"))}
                         period_s = lkp["pairs_per_launch"] / out["value"]

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libicelk.so")
+# ICELK_LIBRARY: another build of this same library (A/B measurements of kernel variants: tools/build_variant.sh)
+LIB_PATH = os.environ.get("ICELK_LIBRARY") or os.path.join(_HERE, "libicelk.so")
 
 OK, EARG, ENOMEM, EHIP, ECAP, ESTATE = 0, -1, -2, -3, -4, -5
 

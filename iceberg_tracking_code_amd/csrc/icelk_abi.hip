@@ -105,6 +105,7 @@ struct Ctx {
         DetectScratch D{};
         DetectJob job{};
         int* h_counts = nullptr;
+        int counts_seq = 0;               // h_counts[kCountsSeq] == counts_seq: the counts published last have arrived
         hipEvent_t counts_ev = nullptr;   // h_counts holds the counts of this set's detection
         hipEvent_t tail_done = nullptr;   // the tail of this set's latest detection (sort, emit, counter reset) is through
         size_t reset_ncell = 0;
@@ -112,6 +113,7 @@ struct Ctx {
         int eo_active = 0;
     } dset[2];
     hipEvent_t counts_ev = nullptr, tail_done = nullptr;
+    int counts_seq = 0;
     hipStream_t tail_stream = nullptr;     // see detect_finish
     int dset_cur = 0;
     unsigned long long job_seq = 0;
@@ -740,15 +742,19 @@ static void destroy_ctx(Ctx* c)
 // detect_begin enqueues K6..K8 on the detection stream and returns at once; detect_finish waits for the
 // counts, sorts the accepted corners and leaves the first *n_out of them in c->d_corners (device), in
 // response order.
+constexpr int kCountsSeq = 8;   // word of the pinned counts that carries the sequence number of the publication
 __global__ void k_publish_counts(const int* __restrict__ cand, const int* __restrict__ acc,
                                  const int* __restrict__ undecided, const unsigned* __restrict__ prune_key,
-                                 int* __restrict__ host_out)
+                                 int* __restrict__ host_out, int seq)
 {
     host_out[0] = *cand;
     host_out[1] = *acc;
     host_out[2] = *undecided;
     host_out[3] = (int)(*prune_key != 0u);
     __threadfence_system();
+    // the host polls this word (fetch_counts): it learns of the counts when they land in its memory, not when the
+    // runtime has processed the completion signal of an event behind this kernel and woken the waiting thread
+    __hip_atomic_store(host_out + kCountsSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 static void det_save(Ctx* c)
@@ -757,6 +763,7 @@ static void det_save(Ctx* c)
     S.D = c->D;
     S.job = c->job;
     S.h_counts = c->h_counts;
+    S.counts_seq = c->counts_seq;
     S.counts_ev = c->counts_ev;
     S.tail_done = c->tail_done;
     S.reset_ncell = c->reset_ncell;
@@ -771,6 +778,7 @@ static void det_load(Ctx* c, int k)
     c->D = S.D;
     c->job = S.job;
     c->h_counts = S.h_counts;
+    c->counts_seq = S.counts_seq;
     c->counts_ev = S.counts_ev;
     c->tail_done = S.tail_done;
     c->reset_ncell = S.reset_ncell;
@@ -824,17 +832,39 @@ static int eo_free(Ctx* c, const Ctx::EigOut* want)
 static int publish_counts(Ctx* c)
 {
     const DetectJob& J = c->job;
+    c->counts_seq = (c->counts_seq + 1) & 0x3fffffff;
     hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(1), 0, c->det_stream, J.cand_count_ptr, c->D.acc_count,
-                       c->D.undecided + suppress_launch_count() - 1, c->D.prune_key, c->h_counts);
+                       c->D.undecided + suppress_launch_count() - 1, c->D.prune_key, c->h_counts, c->counts_seq);
     HIPCHK(c, hipEventRecord(c->counts_ev, c->det_stream));
     return ICELK_OK;
 }
 
+// have the counts published last arrived?  (the sequence word, no runtime call)
+static inline bool counts_here(const int* h_counts, int seq)
+{
+    return __atomic_load_n(h_counts + kCountsSeq, __ATOMIC_ACQUIRE) == seq;
+}
+
+// Waits for the counts by polling the pinned sequence word; the event is looked at now and then, so that a failed
+// kernel ends the wait with its error instead of hanging it (ICELK_EVENT_WAIT=1: hipEventSynchronize, as before).
 static int fetch_counts(Ctx* c, bool published = false)
 {
     if (!published) {
         int rc = publish_counts(c);
         if (rc) return rc;
+    }
+    static const bool by_event = getenv("ICELK_EVENT_WAIT") != nullptr;
+    if (!by_event) {
+        for (unsigned it = 1;; it++) {
+            if (counts_here(c->h_counts, c->counts_seq)) return ICELK_OK;
+            if ((it & 4095u) == 0) {
+                const hipError_t q = hipEventQuery(c->counts_ev);
+                if (q == hipSuccess) break;             // complete: the synchronize below returns at once
+                if (q != hipErrorNotReady) HIPCHK(c, q);
+                (void)hipGetLastError();
+            }
+            __builtin_ia32_pause();
+        }
     }
     HIPCHK(c, hipEventSynchronize(c->counts_ev));
     return ICELK_OK;
@@ -1394,6 +1424,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         c->err = "hipStreamCreate failed";
         return fail(ICELK_EHIP);
     }
+    memset(c->h_counts, 0, 64);
     c->stream = c->own_stream;
     c->slots.resize(n_slots);
     const size_t sb = slot_bytes(max_w, max_h);
@@ -1522,6 +1553,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
             c->err = "hipHostMalloc failed";
             return fail(ICELK_EHIP);
         }
+        memset(S.h_counts, 0, 64);
         S.eo_active = 1;
         E.raw = c->eo[1].raw;
         E.blk_count = c->eo[1].blk_count;
@@ -2196,12 +2228,14 @@ int icelk_seg_detect_stage_try(icelk_t* h, int max_corners, int* out_n, int* out
     const int k = det_oldest(c);
     if (k < 0) FAIL(c, ICELK_ESTATE, "no detection in flight");
     // the counts of the oldest detection in flight: published behind its min-distance stage (publish_counts)
-    const hipError_t q = hipEventQuery(c->dset[k].counts_ev);
-    if (q == hipErrorNotReady) {
-        (void)hipGetLastError();
-        return ICELK_OK;
+    if (!counts_here(c->dset[k].h_counts, c->dset[k].counts_seq)) {
+        const hipError_t q = hipEventQuery(c->dset[k].counts_ev);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            return ICELK_OK;
+        }
+        HIPCHK(c, q);
     }
-    HIPCHK(c, q);
     int rc = seg_stage(c, max_corners, out_n);
     if (rc) return rc;
     *out_done = 1;

@@ -384,7 +384,14 @@ __global__ __launch_bounds__(256) void k_eig_nms(const uint8_t* __restrict__ img
 //     then the 3x3 non-max test, one thread per column, for the 4 rows whose lower neighbour now exists.
 // Strips that touch the top or bottom of the image (FRESH) reflect rows: the covariance row at a reflected position is
 // the one AT that position with its own neighbours, so the roll does not apply there and each row loads its 3x3 afresh.
-// Halo: 1.045 in x, 73 covariance rows for 62 output rows.  Regions: 4 per workgroup (16 output rows each).
+// Halo: 1.045 in x, 69 covariance rows for 58 output rows.  Regions: 4 per workgroup (16 output rows each).
+// Measured and dropped: a form that stays within the 72 VGPRs the tracker's five waves leave free on a SIMD (ring in
+// LDS, the running sums and the roll parked in LDS during the row-sum phase, s_setprio 3), so that its workgroups are
+// resident the moment they are dispatched instead of waiting for tracker waves to retire on all four SIMDs of a CU.
+// It does what it was built for -- the gaps between tracker launches shrink from 11-200 us to 13-20 us -- but the
+// tracker launch beside it takes 318 us instead of 282 and the kernel alone 154 us instead of 75 (53 KB of LDS, two
+// workgroups per CU): 5 630-5 690 pairs/s against 5 910-5 920 on the same box.  The pipeline is bound by the
+// instructions the SIMDs issue, not by when they issue them.
 // ------------------------------------------------------------------------------------------------
 constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 

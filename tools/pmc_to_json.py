@@ -58,7 +58,7 @@ if lk.get("GRBM_GUI_ACTIVE") and lk.get("SQ_ACTIVE_INST_VALU"):
 def insts(prefix):
     b = next((v for k, v in blocks.items() if k.startswith(prefix) and "workgroups" not in k), None)
     return b.get("SQ_INSTS_VALU") if b else None
-out["beside_valu_insts_per_launch"] = {"k_eig_nms": insts("k_eig_nms"), "k_pyramid_ahead": insts("k_pyramid<3, 64, 64>"),
+out["beside_valu_insts_per_launch"] = {"corner_kernel": insts("k_eig_strip") or insts("k_eig_nms"), "k_pyramid_ahead": insts("k_pyramid<3, 64, 64>"),
                                        "min_distance_chain": sum(insts(k) or 0 for k in ("k_key_hist", "k_key_select", "k_cell_count", "k_scan",
                                                                  "k_cell_fill", "k_suppress", "k_gather_accepted", "k_seg_order", "k_seg_init"))}
 mw = re.search(r"k_lk_fast<(\d+), (\d+), true>", lk_name)
@@ -80,7 +80,7 @@ def mix_ns(path):
     tot = float(sum(v.values()))
     return dict(ns_per_valu_inst=sum(n * cost[k] for k, n in v.items()) / tot, hot_valu_instructions=int(tot),
                 hot_class_share={k: n / tot for k, n in v.items()}, hot_salu_per_valu=hot.get("salu", 0) / tot, source=path)
-out["valu_mix"] = {"tracker": mix_ns("profiles/r03_isa_mix_lk%s.json" % win[0]), "corner_kernel": mix_ns("profiles/r03_isa_mix_eig10.json"),
+out["valu_mix"] = {"tracker": mix_ns("profiles/r03_isa_mix_lk%s.json" % win[0]), "corner_kernel": mix_ns("profiles/r03_isa_mix_strip10.json"),
                    "pyramid_one_wave": mix_ns("profiles/r03_isa_mix_pyr64.json"),
                    "class_cost_source": "profiles/valu_class_cost.json"}
 out["counters_note"] = "counters are from the profiled run named in `source`, not from the run that prints them"
