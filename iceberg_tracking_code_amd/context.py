@@ -318,6 +318,11 @@ class Context:
     def seg_flush(self):
         self._ck(self._lib.icelk_seg_flush(self._h))
 
+    def seg_track_len_hint(self, track_len):
+        """Pairs per segment of the driving loop (0: unknown); lets the last pair of a segment skip leaving templates for a
+        successor that never comes (icelk_seg_track_len_hint).  Results do not depend on it."""
+        self._ck(self._lib.icelk_seg_track_len_hint(self._h, int(track_len)))
+
     def seg_live(self):
         n, tot = C.c_int(0), C.c_int64(0)
         self._ck(self._lib.icelk_seg_live(self._h, C.byref(n), C.byref(tot)))

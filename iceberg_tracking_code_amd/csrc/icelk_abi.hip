@@ -135,7 +135,20 @@ struct Ctx {
         // last launch on the compute stream that touches this set: own event or a shared launch event (see Slot::used)
         hipEvent_t used = nullptr, used_own = nullptr;
         int vert = 0, upper = 0;    // vertices so far, tracks of the segment (= corners detected)
+        // templates the backward pass of the latest pair left in tmpl.buf[set & 1] serve the forward pass of the pair that
+        // writes vertex `tmpl_for` (with the window / levels of tmpl_key); -1: none
+        int tmpl_for = -1, tmpl_key = 0, tmpl_slot = -1;
+        unsigned long long tmpl_gen = 0;
     } sb[kSegSets];
+    // Template reuse between the pairs of a segment (LKBuffers::tmpl_out; k_lk_fast.hip).  Consecutive segments use
+    // consecutive sets, and at most two segments have launches in flight: two tables, picked by the parity of the set.
+    struct {
+        void* buf[2] = {nullptr, nullptr};
+        size_t bytes = 0;          // per table
+        int quads = 0, levels = 0;
+        bool off = false;          // ICELK_NO_TEMPLATE_REUSE, or the tables could not be allocated
+    } tmpl;
+    int track_len_hint = 0;        // icelk_seg_track_len_hint: pairs per segment (0: unknown -- every pair leaves templates)
     // Four sets rotate: the current segment, the one staged for the next switch (sb_cur + 1), the one closed by the
     // latest switch (sb_cur - 1), whose last pair may still be waiting (icelk_seg_track_defer) and whose tracks stay
     // readable (icelk_seg_archive_closed) until the switch after -- and the one before that, which a tracker launch
@@ -656,6 +669,8 @@ static void destroy_ctx(Ctx* c)
         hipFree(c->d_stamps);
     }
     if (c->d_iters) hipFree(c->d_iters);
+    for (void* b : c->tmpl.buf)
+        if (b) hipFree(b);
     for (auto& s : c->slots) {
         if (s.base) hipFree(s.base);
         if (s.ready) hipEventDestroy(s.ready);
@@ -1190,6 +1205,47 @@ static LKJob seg_job(Ctx* c, int set, const Slot& s0, const Slot& s1, const LKPa
     B.seg_vert = S.vert;
     B.seg_max_vert = kMaxVert;
     B.seg_tracked = c->d_tracked;
+    // templates: taken from the pair before if it left them for this vertex, left for the pair after unless this is the
+    // segment's last
+    const int quads = lk_fast_eligible(P) ? lk_template_quads(P.win_w, P.win_h) : 0;
+    const int key = (P.win_w << 16) | (P.win_h << 8) | (P.top_level + 1);
+    // (the templates were built on the frame and pyramid that sat in the pair's second slot: they serve the next pair
+    // only if that very frame is now its first)
+    const int slot0 = (int)(&s0 - c->slots.data()), slot1 = (int)(&s1 - c->slots.data());
+    const bool take = quads > 0 && S.tmpl_for == S.vert && S.tmpl_key == key && S.tmpl_slot == slot0 &&
+                      S.tmpl_gen == s0.gen;
+    S.tmpl_for = -1;
+    if (quads > 0 && !c->tmpl.off) {
+        const bool last = c->track_len_hint > 0 && S.vert >= c->track_len_hint;
+        const size_t need = (size_t)c->max_pts * (size_t)(P.top_level + 1) * ((size_t)quads * 64) * 16;
+        if (!last && need > c->tmpl.bytes) {   // (then nothing was left for this key: `take` is false)
+            for (void*& b : c->tmpl.buf) {
+                if (b) hipFree(b);
+                b = nullptr;
+            }
+            c->tmpl.bytes = 0;
+            for (Ctx::SegBuf& o : c->sb) o.tmpl_for = -1;
+            if (hipMalloc(&c->tmpl.buf[0], need) == hipSuccess && hipMalloc(&c->tmpl.buf[1], need) == hipSuccess) {
+                c->tmpl.bytes = need;
+            } else {
+                (void)hipGetLastError();
+                if (c->tmpl.buf[0]) hipFree(c->tmpl.buf[0]);
+                c->tmpl.buf[0] = c->tmpl.buf[1] = nullptr;
+                c->tmpl.off = true;   // no room: every pair builds its own templates, as before
+            }
+        }
+        if (c->tmpl.bytes >= need) {
+            B.tmpl_levels = P.top_level + 1;
+            if (take) B.tmpl_in = c->tmpl.buf[set & 1];
+            if (!last) {
+                B.tmpl_out = c->tmpl.buf[set & 1];
+                S.tmpl_for = S.vert + 1;
+                S.tmpl_key = key;
+                S.tmpl_slot = slot1;
+                S.tmpl_gen = s1.gen;
+            }
+        }
+    }
     return j;
 }
 
@@ -1275,7 +1331,10 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
         // tiles (half window + search margin) of a feature this close to the edge reach over it at the upper levels
         c->border_px = c->border_first ? ((std::max(win_w, win_h) / 2 + kLkTileMargin + 2) << std::max(P.top_level - 1, 0)) : 0;
         LKJob job = seg_job(c, c->sb_cur, s0, s1, P, true);
-        const bool diag = c->d_stamps != nullptr;   // workgroup stamps describe ONE job: no pairing while they are on
+        // workgroup stamps describe ONE job: no pairing while they are on -- unless ICELK_LK_STAMPS_PAIR asks for the
+        // stamps of a joint launch (indexed by workgroup: tools/lk_stamps_pair.py tells the jobs apart)
+        static const bool stamp_pairs = getenv("ICELK_LK_STAMPS_PAIR") != nullptr;
+        const bool diag = c->d_stamps != nullptr && !stamp_pairs;
         if (defer && !c->defer.pending && !diag) {
             // nothing goes out now: the pair waits for the first pair of the next segment (or another waiting pair)
             Ctx::Deferred& d = c->defer;
@@ -1296,6 +1355,10 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
                 // the diagnostic arrays belong to the job of the current segment
                 other.B.p_fwd = other.B.p_bwd = other.B.err_fwd = other.B.err_bwd = other.B.dist = nullptr;
                 other.B.st_fwd = other.B.st_bwd = other.B.valid = nullptr;
+                if (c->d_stamps && stamp_pairs && (size_t)(other.n + job.n + 32) <= c->stamps_cap) {
+                    other.B.stamps = job.B.stamps = c->d_stamps;
+                    hipMemsetAsync(c->d_stamps, 0, 3 * c->stamps_cap * 8, c->stream);
+                }
                 {
                     ProfScope p(c, K_LK_FB_PAIR);
                     paired = launch_lk_pair(c->stream, other, job, P);
@@ -1318,7 +1381,7 @@ static int seg_track_core(Ctx* c, int slot_prev, int slot_next, int win_w, int w
                 c->iters_n = S.upper;
                 hipMemsetAsync(c->d_iters, 0xff, sizeof(uint32_t) * (size_t)S.upper, c->stream);   // dead tracks stay ~0
             }
-            if (c->d_stamps) {
+            if (c->d_stamps && !stamp_pairs) {
                 B.stamps = c->d_stamps;
                 hipMemsetAsync(c->d_stamps, 0, 3 * c->stamps_cap * 8, c->stream);
             }
@@ -1501,6 +1564,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
     c->border_first = getenv("ICELK_NO_BORDER_FIRST") == nullptr;
     c->pyr_per_level = getenv("ICELK_PYR_PER_LEVEL") != nullptr;
     c->pyr_ahead_one_wave = getenv("ICELK_PYR_AHEAD_WIDE") == nullptr;
+    c->tmpl.off = getenv("ICELK_NO_TEMPLATE_REUSE") != nullptr;
     if (!c->border_first) c->border_px = 0;
     if ((rc = dmalloc(c, &c->d_iters, (size_t)max_pts))) return fail(rc);
     if (const char* sp = getenv("ICELK_LK_STAMPS")) {
@@ -2205,6 +2269,7 @@ static int seg_switch(Ctx* c)
     c->sb_cur = (c->sb_cur + 1) % kSegSets;
     c->seg_ready_pending = true;
     c->sb[c->sb_cur].vert = 1;
+    c->sb[c->sb_cur].tmpl_for = -1;
     c->sb[c->sb_cur].upper = c->staged_n;
     c->seg_active = true;
     return ICELK_OK;
@@ -2306,6 +2371,13 @@ int icelk_seg_track_defer(icelk_t* h, int slot_prev, int slot_next, int win_w, i
     HIPCHK(c, hipSetDevice(c->device));
     return seg_track_core(c, slot_prev, slot_next, win_w, win_h, max_level, crit_type, max_count, epsilon,
                           min_eig_threshold, fb_threshold, true);
+}
+
+int icelk_seg_track_len_hint(icelk_t* h, int track_len)
+{
+    if (!h || track_len < 0) return ICELK_EARG;
+    C(h)->track_len_hint = track_len;
+    return ICELK_OK;
 }
 
 int icelk_seg_flush(icelk_t* h)

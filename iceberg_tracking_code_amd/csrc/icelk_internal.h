@@ -118,7 +118,19 @@ struct LKBuffers {
     unsigned long long* stamps;
     // measurement (icelk_prof_enable): LK iterations each feature ran, forward pass in the low half, backward in the high
     uint32_t* iters;
+    // Template reuse across the pairs of a segment (window-specialised kernels only; see k_lk_fast.hip): the BACKWARD pass
+    // of pair v builds, at every level, the template of frame v+1 at the position the forward pass of pair v+1 starts
+    // from -- the same patch, derivatives and 2x2 matrix.  tmpl_out: where the backward pass leaves them; tmpl_in: where
+    // the forward pass of this launch finds the ones of the launch before (null: built here).
+    // Layout: [track][level][quad][lane] 16-byte pieces; the dword behind a lane's template carries A11 / A12 / A22 (lanes 0-2).
+    void* tmpl_out;
+    const void* tmpl_in;
+    int tmpl_levels;     // levels per track in those tables (top_level + 1 of the launch that wrote them)
 };
+// 16-byte pieces per lane and level of a stored template for this window (0: no window-specialised kernel, no reuse)
+int lk_template_quads(int win_w, int win_h);
+// will launch_lk / launch_lk_pair run the window-specialised one-feature-per-wave kernel for these parameters?
+bool lk_fast_eligible(const LKParams& P);
 // search-tile margin of the window-specialised tracker kernels (lk_fast_tiles.h); the host needs it to tell which features'
 // tiles reach over the frame border
 constexpr int kLkTileMargin = 1;

@@ -37,12 +37,106 @@ __device__ __forceinline__ float sum_to_float(long long t)
     return __fadd_rn(__fmul_rn((float)hi, 65536.f), (float)lo);
 }
 
+// A template as it travels from the backward pass of one pair to the forward pass of the next (LKBuffers::tmpl_out):
+// the lane's registers, flattened to dwords -- Ineg, then the packed gradient pairs -- in 16-byte pieces.
+template <int WW, int WH>
+struct TmplIO {
+    using C = Cfg<WW, WH>;
+    static constexpr int HP = (C::S + 1) / 2;
+    static constexpr int PER = C::S + 2 * HP;          // dwords per row segment
+    static constexpr int NDW = C::TPL * PER;
+    // one spare dword behind the template: lanes 0, 1, 2 carry A11, A12, A22 of the level there
+    static constexpr int NQ = (NDW + 1 + 3) / 4;
+    static constexpr int LEVEL = NQ * 64;              // 16-byte pieces per level
+    // Waves per SIMD the kernel is built for (its launch bounds), and whether the LDS landing area of one level's
+    // template (NQ KB per wave) fits beside the tiles at that occupancy: no reuse for a window where it does not
+    static constexpr int WAVES = C::TPL == 1 ? 5 : 3;
+    static constexpr bool FITS = (C::LDS_DW * 4 + NQ * 1024) * 4 * WAVES <= 160 * 1024;
+    static constexpr int LDS_Q = FITS ? NQ * 64 : 1;
+};
+
+template <int WW, int WH>
+__device__ __forceinline__ void tmpl_store(const Template<WW, WH, 1>& T, float A11, float A12, float A22,
+                                           uint4* __restrict__ dst, int lane)
+{
+    using IO = TmplIO<WW, WH>;
+    using C = Cfg<WW, WH>;
+    uint32_t d[IO::NQ * 4];
+#pragma unroll
+    for (int i = 0; i < IO::NQ * 4; i++) d[i] = 0u;
+    d[IO::NDW] = __float_as_uint(lane == 0 ? A11 : (lane == 1 ? A12 : A22));
+#pragma unroll
+    for (int k = 0; k < C::TPL; k++) {
+#pragma unroll
+        for (int j = 0; j < C::S; j++) d[k * IO::PER + j] = (uint32_t)T.Ineg[0][k][j];
+#pragma unroll
+        for (int q = 0; q < IO::HP; q++) {
+            d[k * IO::PER + C::S + q] = T.Ixp[0][k][q];
+            d[k * IO::PER + C::S + IO::HP + q] = T.Iyp[0][k][q];
+        }
+    }
+    // non-temporal both ways (here and the fetch): 15 KB per feature that the next launch reads once must not push the
+    // pyramid levels the search tiles come from out of L2
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int q = 0; q < IO::NQ; q++) {
+        const u4v v = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<u4v*>(dst + q * 64 + lane));
+    }
+}
+
+template <int WW, int WH>
+__device__ __forceinline__ void tmpl_unpack(Template<WW, WH, 1>& T, float& A11, float& A12, float& A22,
+                                            const uint4 (&v)[TmplIO<WW, WH>::NQ])
+{
+    using IO = TmplIO<WW, WH>;
+    using C = Cfg<WW, WH>;
+    uint32_t d[IO::NQ * 4];
+#pragma unroll
+    for (int q = 0; q < IO::NQ; q++) { d[4 * q] = v[q].x; d[4 * q + 1] = v[q].y; d[4 * q + 2] = v[q].z; d[4 * q + 3] = v[q].w; }
+    A11 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)d[IO::NDW], 0));
+    A12 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)d[IO::NDW], 1));
+    A22 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)d[IO::NDW], 2));
+#pragma unroll
+    for (int k = 0; k < C::TPL; k++) {
+#pragma unroll
+        for (int j = 0; j < C::S; j++) T.Ineg[0][k][j] = (int)d[k * IO::PER + j];
+#pragma unroll
+        for (int q = 0; q < IO::HP; q++) {
+            T.Ixp[0][k][q] = d[k * IO::PER + C::S + q];
+            T.Iyp[0][k][q] = d[k * IO::PER + C::S + IO::HP + q];
+        }
+    }
+}
+
+// tio: this feature's stored templates (TmplIO::LEVEL pieces per level).  tmode 2: this pass leaves the templates and
+// 2x2 matrices it builds there.  tmode 1: the ones the backward pass of the pair before left there are used instead of
+// building them -- fetched straight into LDS (global_load_lds_dwordx4: no registers, nothing waits), a level ahead:
+// the request for level l-1 goes out when level l has been taken over into registers, and arrives while level l iterates.
 template <int WW, int WH>
 __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const Pyramid& PJ, float p0x, float p0y,
                                                         const LKParams& P, uint32_t* ldsI, uint32_t* ldsJ, int lane,
-                                                        bool want_err)
+                                                        bool want_err, uint4* __restrict__ tio, int tmode, uint4* tlds)
 {
     using C = Cfg<WW, WH>;
+    using IO = TmplIO<WW, WH>;
+    const bool reuse = IO::FITS && tmode == 1;   // the same for every lane
+    int in_lds = -1;                             // level whose template is in (or on its way into) tlds
+    auto fetch = [&](int level) {
+        // piece q of the lane: q KB further on both sides -- the instruction's immediate offset moves the global and the
+        // LDS address alike, so four pieces share one address register and one M0
+        // (the level's base as a scalar pair, the lane as a 32-bit offset: no 64-bit address sits in vector registers)
+        const unsigned long long sb = reinterpret_cast<unsigned long long>(tio + level * IO::LEVEL);
+        const uint4* src = reinterpret_cast<const uint4*>(((unsigned long long)(unsigned)uni((int)(sb >> 32)) << 32) |
+                                                          (unsigned)uni((int)sb)) + lane;
+        static_for<IO::NQ>([&](auto qq) {
+            constexpr int q = qq, grp = q / 4, in = q % 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + grp * 256),
+                                             (__attribute__((address_space(3))) void*)(tlds + grp * 256), 16, in * 1024, 2 /* nt */);
+        });
+        in_lds = uni(level);
+    };
+    if (reuse) fetch(P.top_level);
     constexpr int S = C::S;
     constexpr int R = kMargin;
     const float half_x = (WW - 1) * 0.5f, half_y = (WH - 1) * 0.5f;
@@ -105,24 +199,39 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
             TileRegs<C::JPD, C::JTH> tj;
             // tiles over the frame border take the reflecting loader; either way every load of the level is in flight
             // before the first LDS write waits for one
-            if (i_inside) tile_issue(ti, LI, ix0, iy0, lane);
-            else tile_issue_reflect(ti, LI, ix0, iy0, lane);
+            if (!reuse) {
+                if (i_inside) tile_issue(ti, LI, ix0, iy0, lane);
+                else tile_issue_reflect(ti, LI, ix0, iy0, lane);
+            }
             if (j_inside) tile_issue(tj, LJ, tjx, tjy, lane);
             else if (j_ok) tile_issue_reflect(tj, LJ, tjx, tjy, lane);
-            tile_commit(ti, ldsI, lane);
+            if (!reuse) tile_commit(ti, ldsI, lane);
             if (j_ok) tile_commit(tj, ldsJ, lane);
             if (j_ok) { jx0 = tjx; jy0 = tjy; staged = true; }
             __syncthreads();
         }
 
         // ---- template patch into registers (lk_fast_tiles.h) ------------------------------------------
-        int a11, a12, a22;
-        template_pixels<WW, WH, 1, 0>(T, ldsI, (uint32_t)uni((int)pack_weights_lo(wi)), (uint32_t)uni((int)pack_weights_hi(wi)),
-                                      ix0 & 3, i_inside, ipx, ipy, LI.w, LI.h, trow, tcol, pmask, a11, a12, a22);
-        // |Ix*Ix| <= 4080^2 per pixel: 16-lane sums fit int32 while a lane holds <= 8 pixels
-        const float A11 = sum_to_float(sum_pick<kSmall, 16>(a11)) * FLT_SCALE;
-        const float A12 = sum_to_float(sum_pick<kSmall, 16>(a12)) * FLT_SCALE;
-        const float A22 = sum_to_float(sum_pick<kSmall, 16>(a22)) * FLT_SCALE;
+        float A11, A12, A22;
+        if (reuse) {
+            if (in_lds != level) fetch(level);              // a level above was left before its template was needed
+            __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the pieces have landed
+            uint4 tq[IO::NQ];
+#pragma unroll
+            for (int q = 0; q < IO::NQ; q++) tq[q] = tlds[q * 64 + lane];
+            tmpl_unpack<WW, WH>(T, A11, A12, A22, tq);
+            __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): read out before the next level overwrites it
+            if (level > 0) fetch(level - 1);
+        } else {
+            int a11, a12, a22;
+            template_pixels<WW, WH, 1, 0>(T, ldsI, (uint32_t)uni((int)pack_weights_lo(wi)), (uint32_t)uni((int)pack_weights_hi(wi)),
+                                          ix0 & 3, i_inside, ipx, ipy, LI.w, LI.h, trow, tcol, pmask, a11, a12, a22);
+            // |Ix*Ix| <= 4080^2 per pixel: 16-lane sums fit int32 while a lane holds <= 8 pixels
+            A11 = sum_to_float(sum_pick<kSmall, 16>(a11)) * FLT_SCALE;
+            A12 = sum_to_float(sum_pick<kSmall, 16>(a12)) * FLT_SCALE;
+            A22 = sum_to_float(sum_pick<kSmall, 16>(a22)) * FLT_SCALE;
+        }
+        if (IO::FITS && tmode == 2) tmpl_store<WW, WH>(T, A11, A12, A22, tio + level * IO::LEVEL, lane);
         float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
         const float dif = __fsub_rn(A11, A22);
         const float rad = __fadd_rn(__fmul_rn(dif, dif), __fmul_rn(__fmul_rn(4.f, A12), A12));
@@ -236,23 +345,34 @@ struct LKJobs {
 };
 
 template <int WW, int WH, bool FB>
-// Waves per SIMD the register allocation aims at: 21x21 needs 86 VGPRs (5 waves fit), 31x31 144 (3), 35x35 180 -- held to
-// 168 for a third wave at the price of 16 B of scratch: REF 654 -> 770 pairs/s.  Forcing more (21x21 at 8, 31x31 at 4) spills
-// into the loops and loses.
-__global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : 3)) void k_lk_fast(LKJobs JJ, LKParams P)
+__device__ __forceinline__ void lk_fast_body(const LKJobs& JJ, const LKParams& P)
 {
     using C = Cfg<WW, WH>;
     __shared__ uint32_t lds[C::LDS_DW];
+    __shared__ uint4 tlds[TmplIO<WW, WH>::LDS_Q];   // landing area of one level's stored template
     int which = 0, b = blockIdx.x;
     if (JJ.g1 > 0) {
+        // The hardware deals the workgroups of a launch to the CUs of an XCD ROUND ROBIN, by count -- not to whichever CU
+        // has a slot free (tools/lk_stamps_pair.py: every CU gets 76-80 of the 20 016 workgroups whatever they take).
+        // Alternating the jobs group by group therefore gave all workgroups of one job to the even CUs and the other job's
+        // to the odd ones (32 CUs per XCD, period 2): 128 CUs per job, and the launch lasted as long as the slower job
+        // on half the chip.  Blocks of 32 groups (one workgroup per CU of every XCD) alternate instead, so that every CU
+        // works through both jobs; what is left of the shorter job after its whole blocks alternates group by group.
         const int G = b >> 3, m = (JJ.g0 < JJ.g1 ? JJ.g0 : JJ.g1) >> 3;   // groups interleaved per job
-        if (G < 2 * m) {
-            which = G & 1;
-            b = ((G >> 1) << 3) | (b & 7);
+        const int mb = m & ~31;
+        int Gj;
+        if (G < 2 * mb) {
+            which = (G >> 5) & 1;
+            Gj = ((G >> 6) << 5) | (G & 31);
+        } else if (G < 2 * m) {
+            const int r = G - 2 * mb;
+            which = r & 1;
+            Gj = mb + (r >> 1);
         } else {
             which = JJ.g0 < JJ.g1 ? 1 : 0;
-            b = ((G - m) << 3) | (b & 7);
+            Gj = G - m;
         }
+        b = (Gj << 3) | (b & 7);
     }
     const LKJob& J = JJ.job[which];
     const LKBuffers& B = J.B;
@@ -265,7 +385,11 @@ __global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : 3)) void k_lk_fast
     uint32_t* ldsJ = lds + C::I_DW;
     const float p0x = B.p_in[2 * f], p0y = B.p_in[2 * f + 1];
     if (lane == 0) stamp(B, 0);
-    const TrackResult r1 = track_point_fast<WW, WH>(J.I, J.J, p0x, p0y, P, ldsI, ldsJ, lane, B.err_fwd != nullptr);
+    using IO = TmplIO<WW, WH>;
+    const size_t t_off = (size_t)f * ((size_t)B.tmpl_levels * IO::LEVEL);   // pieces before this track's
+    const TrackResult r1 = track_point_fast<WW, WH>(J.I, J.J, p0x, p0y, P, ldsI, ldsJ, lane, B.err_fwd != nullptr,
+                                                    const_cast<uint4*>(static_cast<const uint4*>(B.tmpl_in)) + t_off,
+                                                    B.tmpl_in ? 1 : 0, tlds);
     if (lane == 0) {
         if (B.p_fwd) { B.p_fwd[2 * f] = r1.x; B.p_fwd[2 * f + 1] = r1.y; }
         if (B.st_fwd) B.st_fwd[f] = (uint8_t)r1.status;
@@ -273,7 +397,8 @@ __global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : 3)) void k_lk_fast
         if (B.iters && !FB) B.iters[f] = (uint32_t)r1.iters;
     }
     if (FB) {
-        const TrackResult r2 = track_point_fast<WW, WH>(J.J, J.I, r1.x, r1.y, P, ldsI, ldsJ, lane, B.err_bwd != nullptr);
+        const TrackResult r2 = track_point_fast<WW, WH>(J.J, J.I, r1.x, r1.y, P, ldsI, ldsJ, lane, B.err_bwd != nullptr,
+                                                        static_cast<uint4*>(B.tmpl_out) + t_off, B.tmpl_out ? 2 : 0, tlds);
         if (lane == 0) {
             if (B.p_bwd) { B.p_bwd[2 * f] = r2.x; B.p_bwd[2 * f + 1] = r2.y; }
             if (B.st_bwd) B.st_bwd[f] = (uint8_t)r2.status;
@@ -288,6 +413,25 @@ __global__ __launch_bounds__(64, (Cfg<WW, WH>::TPL == 1 ? 4 : 3)) void k_lk_fast
     if (lane == 0) stamp(B, 1);
 }
 
+// Waves per SIMD the register allocation aims at: 21x21 needs 86 VGPRs (5 waves fit), 31x31 144 (3), 35x35 180 -- held to
+// 168 for a third wave at the price of 16 B of scratch: REF 654 -> 770 pairs/s.  Forcing more (21x21 at 8, 31x31 at 4) spills
+// into the loops and loses.
+template <int WW, int WH, bool FB>
+__global__ __launch_bounds__(64, 3) void k_lk_fast(LKJobs JJ, LKParams P)
+{
+    lk_fast_body<WW, WH, FB>(JJ, P);
+}
+
+// One row segment per lane (21x21, 15x15): held to 88 VGPRs.  Five waves of 88 leave 72 registers of a SIMD free, and the
+// kernels that run beside a tracker launch (one-wave pyramid: 70, the min-distance chain) fit into those without waiting
+// for a tracker wave to retire; with the template reuse the allocator would otherwise take 93 (still five waves, but 32
+// left over: the reuse then loses more than it wins).  amdgpu_num_vgpr counts half of the unified VGPR+AGPR file.
+template <int WW, int WH, bool FB>
+__global__ __launch_bounds__(64, 4) __attribute__((amdgpu_num_vgpr(44))) void k_lk_fast88(LKJobs JJ, LKParams P)
+{
+    lk_fast_body<WW, WH, FB>(JJ, P);
+}
+
 int grid_of(const LKBuffers& B, int n) { return B.order ? (n + 15) & ~7 : (n + 7) & ~7; }
 
 template <int WW, int WH>
@@ -299,8 +443,13 @@ void launch_fast(hipStream_t s, const LKJob& a, const LKJob* b, const LKParams& 
     JJ.g0 = grid_of(a.B, a.n);
     JJ.g1 = b ? grid_of(b->B, b->n) : 0;
     const int grid = JJ.g0 + JJ.g1;
-    if (fb) hipLaunchKernelGGL((k_lk_fast<WW, WH, true>), dim3(grid), dim3(64), 0, s, JJ, P);
-    else hipLaunchKernelGGL((k_lk_fast<WW, WH, false>), dim3(grid), dim3(64), 0, s, JJ, P);
+    if constexpr (Cfg<WW, WH>::TPL == 1) {
+        if (fb) hipLaunchKernelGGL((k_lk_fast88<WW, WH, true>), dim3(grid), dim3(64), 0, s, JJ, P);
+        else hipLaunchKernelGGL((k_lk_fast88<WW, WH, false>), dim3(grid), dim3(64), 0, s, JJ, P);
+    } else {
+        if (fb) hipLaunchKernelGGL((k_lk_fast<WW, WH, true>), dim3(grid), dim3(64), 0, s, JJ, P);
+        else hipLaunchKernelGGL((k_lk_fast<WW, WH, false>), dim3(grid), dim3(64), 0, s, JJ, P);
+    }
 }
 
 bool dispatch_fast(hipStream_t s, const LKJob& a, const LKJob* b, const LKParams& P, bool fb)
@@ -315,6 +464,21 @@ bool dispatch_fast(hipStream_t s, const LKJob& a, const LKJob* b, const LKParams
 }
 
 }  // namespace
+
+int lk_template_quads(int win_w, int win_h)
+{
+    if (win_w == 21 && win_h == 21) return TmplIO<21, 21>::FITS ? TmplIO<21, 21>::NQ : 0;
+    if (win_w == 31 && win_h == 31) return TmplIO<31, 31>::FITS ? TmplIO<31, 31>::NQ : 0;
+    if (win_w == 35 && win_h == 35) return TmplIO<35, 35>::FITS ? TmplIO<35, 35>::NQ : 0;
+    if (win_w == 15 && win_h == 15) return TmplIO<15, 15>::FITS ? TmplIO<15, 15>::NQ : 0;
+    return 0;
+}
+
+bool lk_fast_eligible(const LKParams& P)
+{
+    if (P.flags & (ICELK_FLAG_INITIAL_FLOW | ICELK_FLAG_GENERIC_KERNEL | ICELK_FLAG_MULTI_PER_WAVE)) return false;
+    return P.sum_mode == 0 && lk_template_quads(P.win_w, P.win_h) > 0;
+}
 
 // Returns true when a specialised kernel exists for this window (and INITIAL_FLOW is not requested).
 bool launch_lk_fast(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers& B, int n, const LKParams& P,

@@ -78,6 +78,7 @@ __device__ __forceinline__ float i64_to_float(long long t)
 }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 // Exact sum of per-lane int32 partials as int64: the partial is split into a 16-bit low part and a
 // signed high part so that neither 64-lane sum can overflow 32 bits.

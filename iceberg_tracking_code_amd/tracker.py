@@ -62,6 +62,7 @@ class SegmentTracker:
         self.w, self.h = width, height
         self.ctx = ctx if ctx is not None else Context(width, height, n_slots=n_slots, max_pts=max_pts, device=device)
         self.n_slots = self.ctx.n_slots
+        self.ctx.seg_track_len_hint(track_len)    # the last pair of a segment leaves no templates behind
         self.use_mask = mask is not None or mask_polygon is not None
         if mask_polygon is not None:
             # (maskpoly, cropleft, croptop): the mask of s1:285-291 rasterised on the device (camtools.py:184-211)

@@ -244,6 +244,13 @@ int icelk_seg_track_defer(icelk_t* h, int slot_prev, int slot_next, int win_w, i
                           int crit_type, int max_count, double epsilon, double min_eig_threshold,
                           float fb_threshold);
 int icelk_seg_flush(icelk_t* h);
+/* Pairs per segment of the loop that drives this handle (`track_len` of s1_lucaskanade_tracking.py:128,362); 0 = unknown
+ * (the default).  A hint, results never depend on it: the backward pass of pair v of a segment builds, level by level,
+ * exactly the templates (patch, derivatives, 2x2 matrix) that the forward pass of pair v+1 builds again -- frame v+1 at
+ * the positions the tracks have reached -- so the window-specialised kernels leave them in HBM for the next launch
+ * instead.  With the hint the LAST pair of a segment does not write templates nobody will read.
+ * ICELK_NO_TEMPLATE_REUSE=1 turns the reuse off altogether (A/B). */
+int icelk_seg_track_len_hint(icelk_t* h, int track_len);
 int icelk_seg_read_closed(icelk_t* h, float* tracks, float* quality, int cap, int max_vertices, int* out_n,
                           int* out_vertices);
 int icelk_seg_archive_closed(icelk_t* h, void* dev_tracks, void* dev_quality, void* dev_count, int cap_rows,

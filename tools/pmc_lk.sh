@@ -1,12 +1,23 @@
 #!/bin/bash
-# Runs on the GPU box: the two SQ counter passes for the tracker kernel only (quick look while tuning).
-# Usage: tools/pmc_lk.sh <tag> [bench args...]
+# Runs on the GPU box: SQ counters of the tracker launches of the timed steps, for one setting of the environment.
+#   tools/pmc_lk.sh <tag> [VAR=value ...]
 set -u
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+for kv in "$@"; do export "$kv"; done
 O=gpurun_out/$TAG; mkdir -p "$O"
-ARGS="--steps 12 --warmup 4 --no-cpu-baseline --no-kernel-timing $*"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_sq_a -- python3 bench.py $ARGS > $O/pmc_sq_a.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA --output-format csv -d $O/pmc_sq_b -- python3 bench.py $ARGS > $O/pmc_sq_b.log 2>&1
-python3 tools/pmc_summary.py $O/pmc_sq_a $O/pmc_sq_b > $O/pmc_summary.txt 2>&1
-grep -A17 "k_lk" $O/pmc_summary.txt
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc -- python3 bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-kernel-timing > $O/pmc.log 2>&1
+python3 - "$O" <<'PY'
+import csv, glob, sys, collections
+f = glob.glob(sys.argv[1] + "/pmc/**/*_counter_collection.csv", recursive=True)[0]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f)):
+    n = r["Kernel_Name"]
+    if "k_lk_fast" not in n: continue
+    key = "%s grid=%s" % (n.split("(")[0][-30:], r.get("Grid_Size", r.get("Grid_Size_X", "")))
+    acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in acc.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print("   %-22s n=%3d mean=%.4g" % (c, len(v), sum(v) / len(v)))
+PY
