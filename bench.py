@@ -633,6 +633,12 @@ def main():
                 scale = lkp["pairs_per_launch"] / float(pj.get("frame_pairs_per_launch", 1))
                 out["roofline"]["traffic"] = pj.get("lk_fb_bytes_per_launch") * scale if pj.get("lk_fb_bytes_per_launch") else None
                 out["roofline"]["traffic_source"] = pj.get("source")
+                if out["roofline"]["traffic"] and out["roofline"]["traffic"] > 2.0 * alg_pair * lkp["pairs_per_launch"]:
+                    out["roofline"]["traffic_note"] = (
+                        "above the algorithmic bytes on purpose: the backward pass leaves its templates (15 KB per feature and "
+                        "pair at 21x21) in HBM and the next pair's forward pass fetches them instead of rebuilding them -- "
+                        "HBM traffic bought for 9 % fewer vector instructions in a kernel whose HBM fraction is 0.03 "
+                        "(DESIGN.md 4.1; ICELK_NO_TEMPLATE_REUSE=1 turns it off)")
                 vi = pj.get("lk_fb_valu_insts_per_launch")
                 if vi:
                     vi *= scale

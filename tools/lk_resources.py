@@ -19,7 +19,7 @@ for src, base in (("k_lk_fast.hip", "k_lk_fast"), ("k_lk_multi.hip", "k_lk_multi
     for line in txt.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
-            mm = re.search(base + r"ILi(\d+)ELi(\d+)E(?:Li(\d+)E)?Lb([01])E", m.group(1))
+            mm = re.search(base + r"(?:88)?ILi(\d+)ELi(\d+)E(?:Li(\d+)E)?Lb([01])E", m.group(1))   # k_lk_fast88: the 88-VGPR entry point
             cur = None
             if mm:
                 w, h, f, fb = mm.groups()

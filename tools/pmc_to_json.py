@@ -61,7 +61,7 @@ def insts(prefix):
 out["beside_valu_insts_per_launch"] = {"corner_kernel": insts("k_eig_strip") or insts("k_eig_nms"), "k_pyramid_ahead": insts("k_pyramid<3, 64, 64>"),
                                        "min_distance_chain": sum(insts(k) or 0 for k in ("k_key_hist", "k_key_select", "k_cell_count", "k_scan",
                                                                  "k_cell_fill", "k_suppress", "k_gather_accepted", "k_seg_order", "k_seg_init"))}
-mw = re.search(r"k_lk_fast<(\d+), (\d+), true>", lk_name)
+mw = re.search(r"k_lk_fast(?:88)?<(\d+), (\d+), true>", lk_name)
 win = (mw.group(1), mw.group(2)) if mw else ("21", "21")
 res = json.load(open("profiles/r03_lk_resources.json"))
 rk = "k_lk_fast<%s,%s,true>" % win
