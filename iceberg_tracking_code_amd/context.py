@@ -318,6 +318,12 @@ class Context:
     def seg_flush(self):
         self._ck(self._lib.icelk_seg_flush(self._h))
 
+    def seg_template_stats(self):
+        """(pairs whose forward pass took the templates of the pair before, pairs that left templates) -- diagnostics."""
+        out = (C.c_longlong * 2)()
+        self._ck(self._lib.icelk_seg_template_stats(self._h, out))
+        return int(out[0]), int(out[1])
+
     def seg_track_len_hint(self, track_len):
         """Pairs per segment of the driving loop (0: unknown); lets the last pair of a segment skip leaving templates for a
         successor that never comes (icelk_seg_track_len_hint).  Results do not depend on it."""

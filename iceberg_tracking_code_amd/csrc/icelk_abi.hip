@@ -147,6 +147,7 @@ struct Ctx {
         size_t bytes = 0;          // per table
         int quads = 0, levels = 0;
         bool off = false;          // ICELK_NO_TEMPLATE_REUSE, or the tables could not be allocated
+        long long taken = 0, left = 0;   // pairs whose forward pass took templates / whose backward pass left them
     } tmpl;
     int track_len_hint = 0;        // icelk_seg_track_len_hint: pairs per segment (0: unknown -- every pair leaves templates)
     // Four sets rotate: the current segment, the one staged for the next switch (sb_cur + 1), the one closed by the
@@ -1236,8 +1237,12 @@ static LKJob seg_job(Ctx* c, int set, const Slot& s0, const Slot& s1, const LKPa
         }
         if (c->tmpl.bytes >= need) {
             B.tmpl_levels = P.top_level + 1;
-            if (take) B.tmpl_in = c->tmpl.buf[set & 1];
+            if (take) {
+                B.tmpl_in = c->tmpl.buf[set & 1];
+                c->tmpl.taken++;
+            }
             if (!last) {
+                c->tmpl.left++;
                 B.tmpl_out = c->tmpl.buf[set & 1];
                 S.tmpl_for = S.vert + 1;
                 S.tmpl_key = key;
@@ -2377,6 +2382,14 @@ int icelk_seg_track_len_hint(icelk_t* h, int track_len)
 {
     if (!h || track_len < 0) return ICELK_EARG;
     C(h)->track_len_hint = track_len;
+    return ICELK_OK;
+}
+
+int icelk_seg_template_stats(icelk_t* h, long long* out)
+{
+    if (!h || !out) return ICELK_EARG;
+    out[0] = C(h)->tmpl.taken;
+    out[1] = C(h)->tmpl.left;
     return ICELK_OK;
 }
 

@@ -251,6 +251,10 @@ int icelk_seg_flush(icelk_t* h);
  * instead.  With the hint the LAST pair of a segment does not write templates nobody will read.
  * ICELK_NO_TEMPLATE_REUSE=1 turns the reuse off altogether (A/B). */
 int icelk_seg_track_len_hint(icelk_t* h, int track_len);
+/* out[0] = segment pairs of this handle whose forward pass took its templates from the pair before, out[1] = pairs whose
+ * backward pass left templates for a successor (diagnostics; tests/test_gpu_api.py uses it to see the reuse engage and
+ * refuse: a pair whose first frame is not the frame the templates were built on builds its own). */
+int icelk_seg_template_stats(icelk_t* h, long long* out);
 int icelk_seg_read_closed(icelk_t* h, float* tracks, float* quality, int cap, int max_vertices, int* out_n,
                           int* out_vertices);
 int icelk_seg_archive_closed(icelk_t* h, void* dev_tracks, void* dev_quality, void* dev_count, int cap_rows,

@@ -530,3 +530,41 @@ def test_slot_overwritten_while_its_pyramid_is_still_being_built(orc, synth):
         for l, r in enumerate(ref):
             assert np.array_equal(c.download_level(0, l), r), l
     c.close()
+
+
+def test_templates_travel_only_along_a_real_sequence(synth, monkeypatch):
+    """The backward pass of a pair leaves its templates for the forward pass of the next pair (icelk_seg_track_len_hint) --
+    but only a pair whose FIRST frame is the very frame they were built on may take them.  An adversarial order of pairs
+    (the same pair again, a jump, a re-uploaded slot, a pair with other LK parameters, a real continuation) gives,
+    vertex by vertex, the tracks of a handle that never reuses anything; the counters show where the reuse engaged."""
+    from iceberg_tracking_code_amd import Context
+    w, h = 960, 540
+    frames, _ = synth.sequence(w, h, 7, seed=11, max_step_px=2.0)
+    lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
+    lk31 = dict(winSize=(31, 31), maxLevel=3, criteria=(3, 30, 0.01))
+
+    def run(ctx):
+        for i, f in enumerate(frames):
+            ctx.upload_gray(i, f)
+        n = ctx.seg_detect(0, 800, 0.007, 10, False, 10)
+        ctx.seg_track(0, 1, **lk)        # leaves templates of frame 1
+        ctx.seg_track(1, 2, **lk)        # a real continuation: takes them
+        ctx.seg_track(1, 2, **lk)        # the same pair again: the templates at hand are frame 2's -> builds its own
+        ctx.seg_track(4, 5, **lk)        # a jump: frame 4 is not the frame the last pair ended on
+        ctx.upload_gray(5, frames[6])    # the slot the templates were built on gets another frame
+        ctx.seg_track(5, 6, **lk)        # same slot, other content -> builds its own
+        ctx.seg_track(6, 3, **lk31)      # the frame is right, the window is not
+        ctx.seg_track(3, 2, **lk31)      # a real continuation at 31x31: takes them
+        tracks, quality = ctx.seg_read()
+        return n, tracks, quality, ctx.seg_template_stats()
+
+    a = Context(w, h, n_slots=7, max_pts=4096)
+    na, ta, qa, (taken, left) = run(a)
+    a.close()
+    monkeypatch.setenv("ICELK_NO_TEMPLATE_REUSE", "1")
+    b = Context(w, h, n_slots=7, max_pts=4096)
+    nb, tb, qb, off = run(b)
+    b.close()
+    assert na == nb and na > 300 and len(ta) > 100
+    assert np.array_equal(ta, tb) and np.array_equal(qa, qb)
+    assert (taken, left) == (2, 7) and off == (0, 0)
