@@ -1068,9 +1068,12 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
     return ICELK_OK;
 }
 
-static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
+// seg != null (seg_stage): the corners start a segment in that set -- corner list, the segment's tables and the counter
+// reset go out as ONE launch (k_tail) instead of three; *seg_done tells seg_stage that the tables are written
+static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out, Ctx::SegBuf* seg = nullptr, bool* seg_done = nullptr)
 {
     Range rg("icelk detect_finish (host round trip, sort, corner list)");
+    if (seg_done) *seg_done = false;
     {
         const int k = det_oldest(c);
         if (k < 0) FAIL(c, ICELK_ESTATE, "no detection in flight");
@@ -1135,15 +1138,30 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out)
     int n = total;
     if (max_corners > 0 && n > max_corners) n = max_corners;
     if (n > cap || n > c->max_pts) FAIL(c, ICELK_ECAP, "more corners than the output capacity (raise max_pts)");
-    {
-        ProfScope p(c, K_EMIT, ts);
-        launch_emit_corners(ts, sorted, n, J.w, c->d_corners);
+    static const bool split_tail = getenv("ICELK_SPLIT_TAIL") != nullptr;   // A/B: the three launches of before
+    if (seg && !split_tail) {
+        // launches that still touch the segment set (a segment closed two switches ago) must be through
+        if (int rcw = wait_event(c, ts, seg->used)) return rcw;
+        {
+            ProfScope p(c, K_EMIT, ts);
+            launch_tail_fused(ts, sorted, n, c->d_corners, seg->live, seg->alive, seg->tracks, kMaxVert, D, (int)J.ncell, 1);
+        }
+        rc = check_launch(c, "tail");
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->det_done, ts));
+        HIPCHK(c, hipEventRecord(c->tail_done, ts));
+        *seg_done = true;
+    } else {
+        {
+            ProfScope p(c, K_EMIT, ts);
+            launch_emit_corners(ts, sorted, n, J.w, c->d_corners);
+        }
+        rc = check_launch(c, "emit");
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->det_done, ts));
+        launch_detect_reset(ts, D, (int)J.ncell, 1);   // for this set's next detection, which waits for tail_done
+        HIPCHK(c, hipEventRecord(c->tail_done, ts));
     }
-    rc = check_launch(c, "emit");
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->det_done, ts));
-    launch_detect_reset(ts, D, (int)J.ncell, 1);   // for this set's next detection, which waits for tail_done
-    HIPCHK(c, hipEventRecord(c->tail_done, ts));
     c->reset_ncell = J.ncell;
     c->counters_clean = true;
     *n_out = n;
@@ -2242,14 +2260,17 @@ static int seg_stage(Ctx* c, int max_corners, int* out_n)
 {
     if (c->seg_staged) FAIL(c, ICELK_ESTATE, "a staged segment is waiting for icelk_seg_switch");
     int n = 0;
-    int rc = detect_finish(c, max_corners, c->max_pts, &n);
-    if (rc) return rc;
-    // the new segment goes into the set after the current one, on the tail stream right behind the corner list; launches
-    // that still touch that set (a segment closed two switches ago) must be through
+    // the new segment goes into the set after the current one, on the tail stream right behind the corner list
     Ctx::SegBuf& nb = c->sb[(c->sb_cur + 1) % kSegSets];
+    bool tables_written = false;
+    int rc = detect_finish(c, max_corners, c->max_pts, &n, &nb, &tables_written);
+    if (rc) return rc;
     const hipStream_t ds = c->tail_stream;
-    if (int rcw = wait_event(c, ds, nb.used)) return rcw;
-    launch_seg_init(ds, c->d_corners, n, nb.live, nb.alive, nb.tracks, kMaxVert);
+    if (!tables_written) {
+        // launches that still touch that set (a segment closed two switches ago) must be through
+        if (int rcw = wait_event(c, ds, nb.used)) return rcw;
+        launch_seg_init(ds, c->d_corners, n, nb.live, nb.alive, nb.tracks, kMaxVert);
+    }
     if (c->use_order) launch_seg_order(ds, c->d_corners, n, c->job.w, c->job.h, c->border_px, nb.order, nb.order_border);
     rc = check_launch(c, "seg_init");
     if (rc) return rc;

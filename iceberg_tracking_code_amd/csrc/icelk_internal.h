@@ -217,6 +217,9 @@ size_t sort_tmp_bytes(int n);
 void sort_keys_desc(hipStream_t s, DetectScratch& D, const unsigned long long* in, unsigned long long* out,
                     int n);
 void launch_emit_corners(hipStream_t s, const unsigned long long* keys, int n, int w, float* xy);
+// corner list + the new segment's tables + the detector set's counter reset in one launch (k_tail)
+void launch_tail_fused(hipStream_t s, const unsigned long long* keys, int n, float* corners, float* seg_xy,
+                       uint8_t* seg_alive, float* seg_tracks, int max_vert, DetectScratch& D, int ncell, int mode);
 
 // Segment bookkeeping (k_tracks.hip).
 void launch_fb_filter(hipStream_t s, const float* p0, const float* p0r, int n, float thr, int form, float* dist,

@@ -1041,6 +1041,49 @@ __global__ void k_emit(const unsigned long long* __restrict__ keys, int n, int w
     xy[2 * i + 1] = (float)y;
 }
 
+// The tail of a detection whose corners start a segment, in ONE launch instead of three (k_emit, k_detect_reset,
+// k_seg_init): every launch of the tail has to find room beside a tracker launch -- or beside a corner kernel that has the
+// chip to itself -- and the next tracker launch waits for the last of them.  Blocks [0, emit_blocks): corner i from its
+// sorted key -> the corner list AND the new segment's tables (position, alive flag, vertex 0 of its track); the blocks
+// behind them: the counters of the detector set for its next detection (mode as launch_detect_reset).
+__global__ __launch_bounds__(CT) void k_tail(const unsigned long long* __restrict__ keys, int n, float* __restrict__ corners,
+                                             float* __restrict__ seg_xy, uint8_t* __restrict__ seg_alive,
+                                             float* __restrict__ seg_tracks, int max_vert, int emit_blocks,
+                                             int* __restrict__ cell_count, int* __restrict__ cell_fill, int ncell,
+                                             int* __restrict__ chunk_tot, int* __restrict__ undecided,
+                                             int* __restrict__ acc_count, int* __restrict__ cand_count,
+                                             unsigned* __restrict__ max_key, unsigned* __restrict__ key_hist,
+                                             unsigned* __restrict__ prune_key, int full)
+{
+    if ((int)blockIdx.x < emit_blocks) {
+        const int i = blockIdx.x * CT + threadIdx.x;
+        if (i >= n) return;
+        const unsigned idx = (unsigned)keys[i];
+        const float x = (float)(int)(idx & 0xffffu), y = (float)(int)(idx >> 16);
+        corners[2 * i] = x; corners[2 * i + 1] = y;
+        seg_xy[2 * i] = x; seg_xy[2 * i + 1] = y;
+        seg_alive[i] = 1;
+        seg_tracks[((size_t)i * max_vert) * 2] = x;
+        seg_tracks[((size_t)i * max_vert) * 2 + 1] = y;
+        return;
+    }
+    const int i0 = ((int)blockIdx.x - emit_blocks) * CT + threadIdx.x, stride = ((int)gridDim.x - emit_blocks) * CT;
+    for (int i = i0; i <= ncell; i += stride) {
+        cell_count[i] = 0;
+        if (i < ncell) cell_fill[i] = 0;
+        if (i % SCAN_CHUNK == 0) chunk_tot[(i / SCAN_CHUNK) * CHUNK_TOT_STRIDE] = 0;
+    }
+    if (full & 1)
+        for (int i = i0; i < KEY_BINS; i += stride) key_hist[i] = 0;
+    if (i0 < 8) undecided[i0] = 0;
+    if (i0 == 0) {
+        *acc_count = 0;
+        *cand_count = 0;
+        *prune_key = 0;
+        if (full & 2) *max_key = 0;
+    }
+}
+
 void sobel_scale(int block_size, float* k0, float* k1)
 {
     double scale = (double)(1 << 2) * block_size;
@@ -1283,6 +1326,18 @@ void continue_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double
 }
 
 int suppress_launch_count() { return kSuppressLaunches; }
+
+void launch_tail_fused(hipStream_t s, const unsigned long long* keys, int n, float* corners, float* seg_xy,
+                       uint8_t* seg_alive, float* seg_tracks, int max_vert, DetectScratch& D, int ncell, int mode)
+{
+    const int emit_blocks = (n + CT - 1) / CT;
+    int blocks = (ncell + CT) / CT;
+    if ((mode & 1) && blocks < KEY_BINS / CT) blocks = KEY_BINS / CT;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_tail, dim3(emit_blocks + blocks), dim3(CT), 0, s, keys, n, corners, seg_xy, seg_alive, seg_tracks,
+                       max_vert, emit_blocks, D.cell_count, D.cell_fill, ncell, D.chunk_tot, D.undecided, D.acc_count,
+                       D.cand_count, D.max_key, D.key_hist, D.prune_key, mode);
+}
 
 void launch_emit_corners(hipStream_t s, const unsigned long long* keys, int n, int w, float* xy)
 {
