@@ -33,8 +33,13 @@ def test_full_frame_fjord_equals_oracle_and_masks_the_detector(orc, synth):
     a = c.good_features(0, 5000, 0.007, 10, True, 10)
     c.set_mask(want)
     b = c.good_features(0, 5000, 0.007, 10, True, 10)
+    frame = c.download_level(0, 0)
     c.close()
     assert len(a) == 5000 and np.array_equal(a, b)
+    # ... and they are the oracle's corners under that mask, in order (s1:437 with mask=mask): the masked maximum, the
+    # quality threshold derived from it and the candidates of the strip kernel at the full frame size
+    ref = orc.good_features(frame, 5000, 0.007, 10, want, 10)
+    assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(ref, np.float32).reshape(np.asarray(a).shape).view(np.uint8))
     xy = a.reshape(-1, 2).astype(int)
     assert np.all(want[xy[:, 1], xy[:, 0]] == 255)
 
