@@ -1236,16 +1236,23 @@ static LKJob seg_job(Ctx* c, int set, const Slot& s0, const Slot& s1, const LKPa
     S.tmpl_for = -1;
     if (quads > 0 && !c->tmpl.off) {
         const bool last = c->track_len_hint > 0 && S.vert >= c->track_len_hint;
-        const size_t need = (size_t)c->max_pts * (size_t)(P.top_level + 1) * ((size_t)quads * 64) * 16;
+        // sized by the tracks of the segments seen, not by max_pts (a handle made for 2^18 points would set 2 x 4 GB aside
+        // at 21x21): rows for this segment now, rounded up generously when the tables have to grow
+        const size_t per_row = (size_t)(P.top_level + 1) * ((size_t)quads * 64) * 16;
+        const size_t need = (size_t)std::max(S.upper, 1) * per_row;
         if (!last && need > c->tmpl.bytes) {   // (then nothing was left for this key: `take` is false)
+            size_t rows = 16384;
+            while (rows < (size_t)S.upper) rows *= 2;
+            rows = std::min(rows, (size_t)std::max(c->max_pts, 1));
+            const size_t alloc = std::max(rows * per_row, need);
             for (void*& b : c->tmpl.buf) {
                 if (b) hipFree(b);
                 b = nullptr;
             }
             c->tmpl.bytes = 0;
             for (Ctx::SegBuf& o : c->sb) o.tmpl_for = -1;
-            if (hipMalloc(&c->tmpl.buf[0], need) == hipSuccess && hipMalloc(&c->tmpl.buf[1], need) == hipSuccess) {
-                c->tmpl.bytes = need;
+            if (hipMalloc(&c->tmpl.buf[0], alloc) == hipSuccess && hipMalloc(&c->tmpl.buf[1], alloc) == hipSuccess) {
+                c->tmpl.bytes = alloc;
             } else {
                 (void)hipGetLastError();
                 if (c->tmpl.buf[0]) hipFree(c->tmpl.buf[0]);
