@@ -568,3 +568,44 @@ def test_templates_travel_only_along_a_real_sequence(synth, monkeypatch):
     assert na == nb and na > 300 and len(ta) > 100
     assert np.array_equal(ta, tb) and np.array_equal(qa, qb)
     assert (taken, left) == (2, 7) and off == (0, 0)
+
+
+@pytest.mark.parametrize("n_old,n_new", [(90, 3000), (3000, 90), (700, 700), (33, 2049), (2600, 2100)])
+def test_joint_launch_of_unequal_segments_equals_two_launches(synth, n_old, n_new):
+    """The two jobs of a joint tracker launch are dealt to the workgroups in alternating blocks of 32 groups, the rest of
+    the shorter job group by group, what is left of the longer one at the end (k_lk_fast.hip): for segments of very
+    different sizes -- fewer than one block, one block and a bit, either job the longer one -- both segments come out as
+    from two launches of their own."""
+    from iceberg_tracking_code_amd import Context
+    w, h = 1600, 1200
+    frames, _ = synth.sequence(w, h, 4, seed=5, max_step_px=2.0)
+    lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
+
+    def run(joint):
+        c = Context(w, h, n_slots=4, max_pts=4096)
+        for i, f in enumerate(frames):
+            c.upload_gray(i, f)
+        assert c.seg_detect(0, n_old, 0.007, 4, False, 10) == n_old
+        c.seg_track(0, 1, wait=False, **lk)
+        c.seg_detect_begin(2, n_new, 0.007, 4, False, 10)
+        assert c.seg_detect_stage(n_new) == n_new
+        if joint:
+            c.seg_track_defer(1, 2, **lk)
+            c.seg_switch()
+            c.prof_reset(); c.prof_enable(True)
+            c.seg_track(2, 3, wait=False, **lk)
+            c.sync(); c.prof_enable(False)
+            assert "lk_fb_pair" in c.prof_table()
+        else:
+            c.seg_track(1, 2, wait=False, **lk)
+            c.seg_switch()
+            c.seg_track(2, 3, wait=False, **lk)
+        old = c.seg_read(closed=True)
+        new = c.seg_read()
+        c.close()
+        return old, new
+
+    (ta, qa), (tb, qb) = run(True)
+    (tc, qc), (td, qd) = run(False)
+    assert np.array_equal(ta, tc) and np.array_equal(qa, qc) and np.array_equal(tb, td) and np.array_equal(qb, qd)
+    assert len(ta) > n_old // 2 and len(tb) > n_new // 2 and ta.shape[1] == 3 and tb.shape[1] == 2
