@@ -522,3 +522,39 @@ def test_pyramid_of_forty_random_sizes(orc):
             for l, r in enumerate(ref):
                 assert np.array_equal(c.download_level(0, l), r), (w, h, ahead, l)
     c.close()
+
+
+def test_corners_of_forty_random_sizes(orc):
+    """The strip kernel walks strips of 245 x 58 outputs (blockSize 10) with per-thread reflected column offsets, reflected
+    row loads for the strips at the top and bottom, a register ring that the row loop must meet in phase, and regions of 16
+    rows: none of that may depend on the frame sizes the other tests use.  Forty random frames from 3 x 3 to 700 x 500 --
+    narrower than a halo, than one strip, a strip and a pixel, a few strips -- with random texture / flat patches, every
+    fused blockSize, with and without a random mask, uncapped and capped: the corner list of the oracle, in order."""
+    from iceberg_tracking_code_amd import Context
+    rng = np.random.RandomState(77)
+    sizes = [(3, 3), (4, 7), (11, 9), (58, 58), (59, 60), (245, 58), (246, 59), (247, 117), (490, 116), (491, 175), (64, 48)]
+    sizes += [(int(rng.randint(3, 701)), int(rng.randint(3, 501))) for _ in range(29)]
+    c = Context(700, 500, n_slots=1, max_pts=1 << 16)
+    for k, (w, h) in enumerate(sizes):
+        img = rng.randint(0, 256, size=(h, w)).astype(np.uint8)
+        if k % 3 == 0:                       # flat patches: plateaus of equal responses, zeros
+            y0, x0 = rng.randint(0, h), rng.randint(0, w)
+            img[y0:y0 + h // 3 + 1, x0:x0 + w // 3 + 1] = rng.randint(0, 256)
+        if k % 4 == 1:                       # smoother texture: fewer, stronger maxima
+            img = (img // 32 * 32).astype(np.uint8)
+        bs = (3, 5, 7, 10)[k % 4]
+        maxc = 0 if k % 2 else int(rng.randint(1, 400))
+        md = (1, 3, 10)[k % 3]
+        mask = None
+        if k % 5 in (1, 3):
+            mask = (rng.randint(0, 4, size=(h, w)) > 0).astype(np.uint8) * 255
+        c.upload_gray(0, img)
+        if mask is not None:
+            c.set_mask(mask)
+        ref = orc.good_features(img, maxc, 0.01, md, mask, bs)
+        got = c.good_features(0, maxc, 0.01, md, mask is not None, bs)
+        if ref is None or len(ref) == 0:
+            assert got is None or len(got) == 0, (w, h, bs)
+        else:
+            assert got is not None and np.array_equal(np.asarray(got).reshape(-1, 2), np.asarray(ref).reshape(-1, 2)), (w, h, bs, maxc, md, mask is not None)
+    c.close()
