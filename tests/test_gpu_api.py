@@ -609,3 +609,37 @@ def test_joint_launch_of_unequal_segments_equals_two_launches(synth, n_old, n_ne
     (tc, qc), (td, qd) = run(False)
     assert np.array_equal(ta, tc) and np.array_equal(qa, qc) and np.array_equal(tb, td) and np.array_equal(qb, qd)
     assert len(ta) > n_old // 2 and len(tb) > n_new // 2 and ta.shape[1] == 3 and tb.shape[1] == 2
+
+
+@pytest.mark.parametrize("win,levels", [((15, 15), 2), ((21, 21), 4), ((31, 31), 3)])
+def test_template_reuse_changes_nothing(synth, monkeypatch, win, levels):
+    """Segments of three pairs on a small frame (features whose windows hang over the frame edge, pyramid levels narrower
+    than a tile) with every window that takes part in the template hand-over: tracks and qualities with the hand-over
+    equal those without it (ICELK_NO_TEMPLATE_REUSE), and the hand-over did take place."""
+    from iceberg_tracking_code_amd import Context, SegmentTracker
+    w, h, n, T = 400, 300, 10, 3
+    frames, _ = synth.sequence(w, h, n, seed=23, max_step_px=2.5)
+    fp = dict(maxCorners=0, qualityLevel=0.005, minDistance=4, blockSize=5)
+    lk = dict(winSize=win, maxLevel=levels, criteria=(3, 30, 0.01))
+
+    def run():
+        ctx = Context(w, h, n_slots=n, max_pts=8192)
+        for i, f in enumerate(frames):
+            ctx.upload_gray(i, f)
+        trk = SegmentTracker(w, h, T, fp, lk, ctx=ctx)
+        segs = []
+        trk.on_close = lambda first, closed: segs.append((first,) + ctx.seg_read(closed=closed))
+        for i in range(n):
+            trk.push_slot(i, False, *[i + k if i + k < n else None for k in range(1, 7)])
+        trk.flush()
+        ctx.sync()
+        st = ctx.seg_template_stats()
+        trk.close()
+        return segs, st
+
+    a, (taken, left) = run()
+    monkeypatch.setenv("ICELK_NO_TEMPLATE_REUSE", "1")
+    b, off = run()
+    assert len(a) == len(b) >= 2 and off == (0, 0) and taken >= 4 and left >= taken
+    for (fa, ta, qa), (fb, tb, qb) in zip(a, b):
+        assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb) and len(ta) > 50
