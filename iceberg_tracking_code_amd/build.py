@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libicelk.so")
-SOURCES = ["icelk_abi.hip", "k_image.hip", "k_pyramid.hip", "k_lk.hip", "k_lk_fast.hip", "k_lk_multi.hip", "k_corners.hip", "k_corners_fast.hip", "k_sort.hip", "k_tracks.hip", "k_utm.hip", "k_mask.hip", "k_grid.hip"]
+SOURCES = ["icelk_abi.hip", "k_image.hip", "k_pyramid.hip", "k_lk.hip", "k_lk_fast.hip", "k_lk_multi.hip", "k_corners.hip", "k_corners_fast.hip", "k_sort.hip", "k_tail.hip", "k_tracks.hip", "k_utm.hip", "k_mask.hip", "k_grid.hip"]
 HEADERS = [os.path.join(CSRC, "icelk_internal.h"), os.path.join(CSRC, "lk_common.h"), os.path.join(CSRC, "lk_fast_tiles.h"), os.path.join(HERE, "..", "include", "icelk.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",

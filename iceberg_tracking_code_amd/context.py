@@ -324,6 +324,12 @@ class Context:
         self._ck(self._lib.icelk_seg_template_stats(self._h, out))
         return int(out[0]), int(out[1])
 
+    def seg_tail_stats(self):
+        """(segments staged by the device-driven detection tail, segments staged by the host's tail) -- diagnostics."""
+        out = (C.c_longlong * 2)()
+        self._ck(self._lib.icelk_seg_tail_stats(self._h, out))
+        return int(out[0]), int(out[1])
+
     def seg_track_len_hint(self, track_len):
         """Pairs per segment of the driving loop (0: unknown); lets the last pair of a segment skip leaving templates for a
         successor that never comes (icelk_seg_track_len_hint).  Results do not depend on it."""

@@ -13,7 +13,7 @@
 
 namespace icelk {
 
-constexpr int kSegSets = 4;
+constexpr int kSegSets = 6;
 constexpr int kLaunchEvents = 32;
 constexpr int kMaxVert = 17;  // vertices per track kept on the device (track_len <= 16; reference uses 2)
 
@@ -30,6 +30,11 @@ struct DetectJob {
     const int* cand_count_ptr = nullptr;
     int prune_want = 0;   // > 0: top-K pruning is on for this job
     unsigned long long seq = 0;   // order of icelk_seg_detect_begin calls: the oldest job in flight is finished first
+    // device-driven tail (k_tail.hip): enqueued behind the min-distance stage by detect_begin; the corners of this detection
+    // start a segment in set `seg_set`, cut at max_corners
+    bool dev_tail = false;
+    int seg_set = -1;
+    int max_corners = 0;
 };
 
 struct Ctx {
@@ -134,6 +139,7 @@ struct Ctx {
         float* quality = nullptr;   // [track][kMaxVert-1]
         // last launch on the compute stream that touches this set: own event or a shared launch event (see Slot::used)
         hipEvent_t used = nullptr, used_own = nullptr;
+        hipEvent_t ready = nullptr;   // the tables of the segment staged in this set are written (detection or tail stream)
         int vert = 0, upper = 0;    // vertices so far, tracks of the segment (= corners detected)
         // templates the backward pass of the latest pair left in tmpl.buf[set & 1] serve the forward pass of the pair that
         // writes vertex `tmpl_for` (with the window / levels of tmpl_key); -1: none
@@ -150,10 +156,12 @@ struct Ctx {
         long long taken = 0, left = 0;   // pairs whose forward pass took templates / whose backward pass left them
     } tmpl;
     int track_len_hint = 0;        // icelk_seg_track_len_hint: pairs per segment (0: unknown -- every pair leaves templates)
-    // Four sets rotate: the current segment, the one staged for the next switch (sb_cur + 1), the one closed by the
+    // Six sets rotate: the current segment, the one staged for the next switch (sb_cur + 1), the one closed by the
     // latest switch (sb_cur - 1), whose last pair may still be waiting (icelk_seg_track_defer) and whose tracks stay
-    // readable (icelk_seg_archive_closed) until the switch after -- and the one before that, which a tracker launch
-    // may still be working on when the host, a launch ahead of the device, stages the next segment.
+    // readable (icelk_seg_archive_closed) until the switch after, the one before that, which a tracker launch
+    // may still be working on when the host, a launch ahead of the device, stages the next segment -- and, since the tail
+    // of a detection writes the new segment's tables without the host (k_tail.hip), the sets behind the staged one that
+    // the detections in flight (two at most) have reserved (DetectJob::seg_set).
     hipEvent_t launch_ev[kLaunchEvents] = {nullptr};   // one per tracker launch, round robin
     int launch_seq = 0;
     int sb_cur = 0;
@@ -164,8 +172,10 @@ struct Ctx {
         LKJob job{};
         LKParams P{};
     } defer;
-    hipEvent_t seg_ready = nullptr;   // the current set has been initialised (detection stream)
-    bool seg_ready_pending = false;   // ... and the compute stream has not been told to wait for it yet
+    bool seg_ready_pending = false;   // the compute stream has not been told yet to wait for the current set's tables (SegBuf::ready)
+    bool host_tail = false;           // ICELK_HOST_TAIL=1: the tail of every detection through the host, as before round 4 (A/B)
+    int tail_force_status = 0;        // ICELK_TAIL_FORCE_STATUS=1|2: the device verdict is forced to "host's tail" (tests of that path)
+    long long tails_dev = 0, tails_host = 0;   // segments staged by the device-driven tail / by the host's
     bool use_order = true;                 // ICELK_NO_ORDER=1 launches in detector order (A/B measurements)
     // features this close to the frame border count as slow (launched first): from the window and pyramid depth of the
     // latest tracker call; ICELK_NO_BORDER_FIRST=1 turns the class off
@@ -686,9 +696,10 @@ static void destroy_ctx(Ctx* c)
     if (c->corners_free) hipEventDestroy(c->corners_free);
     if (c->det_stream) hipStreamDestroy(c->det_stream);
     if (c->eig_stream) hipStreamDestroy(c->eig_stream);
-    if (c->seg_ready) hipEventDestroy(c->seg_ready);
-    for (auto& b : c->sb)
+    for (auto& b : c->sb) {
         if (b.used_own) hipEventDestroy(b.used_own);
+        if (b.ready) hipEventDestroy(b.ready);
+    }
     for (auto& e : c->launch_ev)
         if (e) hipEventDestroy(e);
     for (auto& e : c->eo)
@@ -702,7 +713,7 @@ static void destroy_ctx(Ctx* c)
     {
         DetectScratch& E = c->dset[c->dset_cur ^ 1].D;     // the other set's own arrays (the working copy's are freed below)
         void* ep[] = {E.cand, E.cand_count, E.cell_count, E.cell_start, E.cell_fill, E.chunk_tot, E.cell_cand, E.state, E.undecided,
-                      E.acc, E.acc_sorted, E.acc_count, E.key_hist, E.prune_key, E.sort_tmp};
+                      E.acc, E.acc_sorted, E.acc_count, E.key_hist, E.prune_key, E.sort_tmp, E.tail_ctl, E.tail_resp, E.tail_bins};
         for (void* q : ep)
             if (q) hipFree(q);
     }
@@ -723,7 +734,8 @@ static void destroy_ctx(Ctx* c)
                     c->d_st_f, c->d_st_b, c->d_valid, c->D.eig, c->D.cand, c->D.cand_count,
                     c->D.cell_count, c->D.cell_start, c->D.cell_fill, c->D.chunk_tot, c->D.cell_cand, c->D.state, c->D.undecided,
                     c->D.acc, c->D.acc_sorted, c->D.acc_count, c->eo[0].raw, c->eo[1].raw, c->eo[0].blk_count, c->eo[1].blk_count,
-                    c->eo[0].max_key, c->eo[1].max_key, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->d_tracked,
+                    c->eo[0].max_key, c->eo[1].max_key, c->D.key_hist, c->D.prune_key, c->D.sort_tmp, c->D.tail_ctl,
+                    c->D.tail_resp, c->D.tail_bins, c->d_tracked,
                     c->d_out_tracks, c->d_out_quality, c->d_proj, c->d_keep};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -969,8 +981,11 @@ static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
     return ICELK_OK;
 }
 
+// for_segment: the corners start a segment (icelk_seg_detect_begin) -- the tail of the detection is then enqueued here, behind
+// the min-distance stage, driven by the device-side counts (k_tail.hip), and writes the segment's tables into the set it
+// reserves; otherwise (icelk_good_features) detect_finish runs the tail after the host round trip
 static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double quality, double min_distance,
-                        int block_size)
+                        int block_size, bool for_segment)
 {
     Range rg("icelk detect_begin (candidates + min-distance stage)");
     int rc = check_slot(c, slot, true);
@@ -1051,18 +1066,48 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
     J.prune_want = 0;
     if (min_distance >= 1 && max_corners > 0 && max_corners <= (1 << 24) && !getenv("ICELK_NO_PRUNE"))
         J.prune_want = (int)std::min(8.0 * max_corners, std::ceil(c->prune_factor * max_corners));
+    J.dev_tail = false;
+    J.seg_set = -1;
+    J.max_corners = max_corners;
+    const bool dev_tail = for_segment && !c->host_tail && min_distance >= 1;
     if (min_distance >= 1) {
         J.cand_count_ptr = D.cell_start + ncell;
         ProfScope p(c, K_SUPPRESS, ds);
-        launch_min_distance(ds, D, w, h, min_distance, quality, J.prune_want);
+        launch_min_distance(ds, D, w, h, min_distance, quality, J.prune_want, dev_tail);
+        if (dev_tail)
+            launch_tail_gather(ds, D, (int)ncell, quality, suppress_launch_count() - 1, max_corners, c->max_pts, c->tail_force_status);
     } else {
         J.cand_count_ptr = D.cand_count;
         launch_flatten(ds, D, quality);
     }
     rc = check_launch(c, "min_distance");
     if (rc) return rc;
-    rc = publish_counts(c);
-    if (rc) return rc;
+    if (dev_tail) {
+        // the set the new segment goes into: behind the current one, the staged one and the one the other detection in
+        // flight has reserved (segments are staged and switched to in the order their detections were begun)
+        const Ctx::DetSet& other = c->dset[c->dset_cur ^ 1];
+        const int ahead = (c->seg_staged ? 1 : 0) + (other.job.active ? 1 : 0);
+        const int target = (c->sb_cur + 1 + ahead) % kSegSets;
+        Ctx::SegBuf& nb = c->sb[target];
+        // launches that still touch that set (a segment closed several switches ago) must be through
+        if (int rcw = wait_event(c, ds, nb.used)) return rcw;
+        c->counts_seq = (c->counts_seq + 1) & 0x3fffffff;
+        {
+            ProfScope p(c, K_EMIT, ds);
+            launch_tail_device(ds, D, quality, nb.live, nb.alive, nb.tracks, kMaxVert, c->use_order ? nb.order : nullptr,
+                               nb.order_border, tail_order_geometry(w, h, c->border_px), tail_reset_of(D, (int)ncell),
+                               c->h_counts, kCountsSeq, c->counts_seq);
+        }
+        rc = check_launch(c, "tail (device-driven)");
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(nb.ready, ds));
+        HIPCHK(c, hipEventRecord(c->counts_ev, ds));
+        J.dev_tail = true;
+        J.seg_set = target;
+    } else {
+        rc = publish_counts(c);
+        if (rc) return rc;
+    }
     J.active = true;
     J.seq = ++c->job_seq;
     return ICELK_OK;
@@ -1070,10 +1115,13 @@ static int detect_begin(Ctx* c, int slot, int use_mask, int max_corners, double 
 
 // seg != null (seg_stage): the corners start a segment in that set -- corner list, the segment's tables and the counter
 // reset go out as ONE launch (k_tail) instead of three; *seg_done tells seg_stage that the tables are written
-static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out, Ctx::SegBuf* seg = nullptr, bool* seg_done = nullptr)
+// *dev_done: the device-driven tail has written everything (tables AND launch order): nothing is left to enqueue
+static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out, Ctx::SegBuf* seg = nullptr, bool* seg_done = nullptr,
+                         bool* dev_done = nullptr)
 {
     Range rg("icelk detect_finish (host round trip, sort, corner list)");
     if (seg_done) *seg_done = false;
+    if (dev_done) *dev_done = false;
     {
         const int k = det_oldest(c);
         if (k < 0) FAIL(c, ICELK_ESTATE, "no detection in flight");
@@ -1090,6 +1138,30 @@ static int detect_finish(Ctx* c, int max_corners, int cap, int* n_out, Ctx::SegB
     DetectScratch& D = c->D;
     int rc = fetch_counts(c, true);   // the one host round trip of a detection: {candidates, accepted, undecided}
     if (rc) return rc;
+    if (J.dev_tail) {
+        // the tail ran on the device already; the host adopts its verdict
+        const int status = c->h_counts[5];
+        if (!seg || seg != &c->sb[J.seg_set] || max_corners != J.max_corners)
+            FAIL(c, ICELK_ESTATE, "the segment staged is not the one its detection was begun for (set / maxCorners differ)");
+        if (status == TAIL_OVERFLOW) FAIL(c, ICELK_ECAP, "more corners than the output capacity (raise max_pts)");
+        if (status == TAIL_OK) {
+            const int total = c->h_counts[1], n = c->h_counts[4];
+            if (n > cap) FAIL(c, ICELK_ECAP, "more corners than the output capacity (raise max_pts)");
+            if (J.prune_want > 0 && max_corners > 0)
+                c->prune_factor = !c->h_counts[3] || total <= 0 ? 8.0 : std::min(8.0, std::max(2.0, 1.5 * (double)c->h_counts[0] / total));
+            c->last_candidates = c->h_counts[0];
+            c->last_accepted = total;
+            c->reset_ncell = J.ncell;
+            c->counters_clean = true;    // k_tail_order left them zeroed
+            c->tails_dev++;
+            *n_out = n;
+            if (seg_done) *seg_done = true;
+            if (dev_done) *dev_done = true;
+            return ICELK_OK;
+        }
+        // not converged / pruned set fell short: the host's tail below, on the counts the device published
+    }
+    c->tails_host++;
     const unsigned long long* sorted = nullptr;
     int total = 0;
     if (J.min_distance >= 1) {
@@ -1174,7 +1246,7 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
     *n_out = 0;
     // begin + finish in one go: the detection finished must be the one begun here
     if (det_oldest(c) >= 0) FAIL(c, ICELK_ESTATE, "a detection is in flight (icelk_seg_detect_begin without _stage / _finish)");
-    int rc = detect_begin(c, slot, use_mask, max_corners, quality, min_distance, block_size);
+    int rc = detect_begin(c, slot, use_mask, max_corners, quality, min_distance, block_size, false);
     if (rc) return rc;
     return detect_finish(c, max_corners, cap, n_out);
 }
@@ -1183,7 +1255,7 @@ static int detect_core(Ctx* c, int slot, int use_mask, int max_corners, double q
 static int seg_wait(Ctx* c)
 {
     if (c->seg_ready_pending) {
-        if (int rcw = wait_event(c, c->stream, c->seg_ready)) return rcw;
+        if (int rcw = wait_event(c, c->stream, c->sb[c->sb_cur].ready)) return rcw;
         c->seg_ready_pending = false;
     }
     return ICELK_OK;
@@ -1507,7 +1579,6 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking) != hipSuccess ||
         create_side_streams(c) != hipSuccess ||
-        hipEventCreateWithFlags(&c->seg_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->eo[0].done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->eo[1].done, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), 64, hipHostMallocMapped) != hipSuccess ||
@@ -1540,7 +1611,8 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         }
     }
     for (auto& S : c->sb) {
-        if (hipEventCreateWithFlags(&S.used_own, hipEventDisableTiming) != hipSuccess) {
+        if (hipEventCreateWithFlags(&S.used_own, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&S.ready, hipEventDisableTiming) != hipSuccess) {
             c->err = "hipEventCreate failed";
             return fail(ICELK_EHIP);
         }
@@ -1574,6 +1646,8 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         (rc = dmalloc(c, &D.acc_count, 1)) || (rc = dmalloc(c, &c->eo[0].blk_count, candidate_blocks(max_w, max_h) * 4)) ||
         (rc = dmalloc(c, &c->eo[1].blk_count, candidate_blocks(max_w, max_h) * 4)) ||
         (rc = dmalloc(c, &D.key_hist, 1 << 16)) || (rc = dmalloc(c, &D.prune_key, 1)) || (rc = dmalloc(c, (uint8_t**)&D.sort_tmp, D.sort_tmp_bytes)) ||
+        (rc = dmalloc(c, &D.tail_ctl, TC_WORDS_)) || (rc = dmalloc(c, &D.tail_resp, tail_resp_words())) ||
+        (rc = dmalloc(c, &D.tail_bins, kTailOrderBins + 2)) ||
         (rc = dmalloc(c, &c->d_tracked, 64)) || (rc = dmalloc(c, &c->d_out_tracks, np * kMaxVert * 2)) ||
         (rc = dmalloc(c, &c->d_out_quality, np * (kMaxVert - 1))))
         return fail(rc);
@@ -1595,6 +1669,8 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
     c->pyr_per_level = getenv("ICELK_PYR_PER_LEVEL") != nullptr;
     c->pyr_ahead_one_wave = getenv("ICELK_PYR_AHEAD_WIDE") == nullptr;
     c->tmpl.off = getenv("ICELK_NO_TEMPLATE_REUSE") != nullptr;
+    c->host_tail = getenv("ICELK_HOST_TAIL") != nullptr;
+    if (const char* fs = getenv("ICELK_TAIL_FORCE_STATUS")) c->tail_force_status = std::min(std::max(atoi(fs), 0), 4);
     if (!c->border_first) c->border_px = 0;
     if ((rc = dmalloc(c, &c->d_iters, (size_t)max_pts))) return fail(rc);
     if (const char* sp = getenv("ICELK_LK_STAMPS")) {
@@ -1632,6 +1708,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         E.cand = nullptr; E.cand_count = nullptr; E.cell_count = nullptr; E.cell_start = nullptr; E.cell_fill = nullptr;
         E.chunk_tot = nullptr; E.cell_cand = nullptr; E.state = nullptr; E.undecided = nullptr; E.acc = nullptr;
         E.acc_sorted = nullptr; E.acc_count = nullptr; E.key_hist = nullptr; E.prune_key = nullptr; E.sort_tmp = nullptr;
+        E.tail_ctl = nullptr; E.tail_resp = nullptr; E.tail_bins = nullptr;
         if ((rc = dmalloc(c, &E.cand, (size_t)D.cand_cap)) || (rc = dmalloc(c, &E.cand_count, 1)) ||
             (rc = dmalloc(c, &E.cell_count, c->ncell_cap)) || (rc = dmalloc(c, &E.cell_start, c->ncell_cap)) ||
             (rc = dmalloc(c, &E.cell_fill, c->ncell_cap)) || (rc = dmalloc(c, &E.chunk_tot, (c->ncell_cap / 2048 + 2) * 32)) ||
@@ -1639,8 +1716,18 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
             (rc = dmalloc(c, &E.undecided, 64)) || (rc = dmalloc(c, &E.acc, (size_t)D.cand_cap)) ||
             (rc = dmalloc(c, &E.acc_sorted, (size_t)D.cand_cap)) || (rc = dmalloc(c, &E.acc_count, 1)) ||
             (rc = dmalloc(c, &E.key_hist, 1 << 16)) || (rc = dmalloc(c, &E.prune_key, 1)) ||
-            (rc = dmalloc(c, (uint8_t**)&E.sort_tmp, D.sort_tmp_bytes)))
+            (rc = dmalloc(c, (uint8_t**)&E.sort_tmp, D.sort_tmp_bytes)) || (rc = dmalloc(c, &E.tail_ctl, TC_WORDS_)) ||
+            (rc = dmalloc(c, &E.tail_resp, tail_resp_words())) || (rc = dmalloc(c, &E.tail_bins, kTailOrderBins + 2)))
             return fail(rc);
+        if (hipMemset(E.tail_resp, 0, sizeof(int) * tail_resp_words()) != hipSuccess ||
+            hipMemset(c->D.tail_resp, 0, sizeof(int) * tail_resp_words()) != hipSuccess ||
+            hipMemset(E.tail_ctl, 0, sizeof(int) * TC_WORDS_) != hipSuccess ||
+            hipMemset(E.tail_bins, 0, sizeof(int) * (kTailOrderBins + 2)) != hipSuccess ||
+            hipMemset(c->D.tail_ctl, 0, sizeof(int) * TC_WORDS_) != hipSuccess ||
+            hipMemset(c->D.tail_bins, 0, sizeof(int) * (kTailOrderBins + 2)) != hipSuccess) {
+            c->err = "hipMemset failed";
+            return fail(ICELK_EHIP);
+        }
         if (hipHostMalloc(reinterpret_cast<void**>(&S.h_counts), 64, hipHostMallocMapped) != hipSuccess ||
             hipEventCreateWithFlags(&S.counts_ev, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming) != hipSuccess) {
@@ -2249,7 +2336,7 @@ int icelk_seg_detect_begin(icelk_t* h, int slot, int use_mask, int max_corners, 
     if (!h) return ICELK_EARG;
     Ctx* c = C(h);
     HIPCHK(c, hipSetDevice(c->device));
-    return detect_begin(c, slot, use_mask, max_corners, quality_level, min_distance, block_size);
+    return detect_begin(c, slot, use_mask, max_corners, quality_level, min_distance, block_size, true);
 }
 
 int icelk_seg_detect_prepare(icelk_t* h, int slot, int use_mask, int block_size)
@@ -2269,20 +2356,22 @@ static int seg_stage(Ctx* c, int max_corners, int* out_n)
     int n = 0;
     // the new segment goes into the set after the current one, on the tail stream right behind the corner list
     Ctx::SegBuf& nb = c->sb[(c->sb_cur + 1) % kSegSets];
-    bool tables_written = false;
-    int rc = detect_finish(c, max_corners, c->max_pts, &n, &nb, &tables_written);
+    bool tables_written = false, dev_done = false;
+    int rc = detect_finish(c, max_corners, c->max_pts, &n, &nb, &tables_written, &dev_done);
     if (rc) return rc;
-    const hipStream_t ds = c->tail_stream;
-    if (!tables_written) {
-        // launches that still touch that set (a segment closed two switches ago) must be through
-        if (int rcw = wait_event(c, ds, nb.used)) return rcw;
-        launch_seg_init(ds, c->d_corners, n, nb.live, nb.alive, nb.tracks, kMaxVert);
+    if (!dev_done) {
+        const hipStream_t ds = c->tail_stream;
+        if (!tables_written) {
+            // launches that still touch that set (a segment closed several switches ago) must be through
+            if (int rcw = wait_event(c, ds, nb.used)) return rcw;
+            launch_seg_init(ds, c->d_corners, n, nb.live, nb.alive, nb.tracks, kMaxVert);
+        }
+        if (c->use_order) launch_seg_order(ds, c->d_corners, n, c->job.w, c->job.h, c->border_px, nb.order, nb.order_border);
+        rc = check_launch(c, "seg_init");
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->corners_free, ds));
+        HIPCHK(c, hipEventRecord(nb.ready, ds));
     }
-    if (c->use_order) launch_seg_order(ds, c->d_corners, n, c->job.w, c->job.h, c->border_px, nb.order, nb.order_border);
-    rc = check_launch(c, "seg_init");
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->corners_free, ds));
-    HIPCHK(c, hipEventRecord(c->seg_ready, ds));
     c->seg_staged = true;
     c->staged_n = n;
     if (out_n) *out_n = n;
@@ -2418,6 +2507,14 @@ int icelk_seg_template_stats(icelk_t* h, long long* out)
     if (!h || !out) return ICELK_EARG;
     out[0] = C(h)->tmpl.taken;
     out[1] = C(h)->tmpl.left;
+    return ICELK_OK;
+}
+
+int icelk_seg_tail_stats(icelk_t* h, long long* out)
+{
+    if (!h || !out) return ICELK_EARG;
+    out[0] = C(h)->tails_dev;
+    out[1] = C(h)->tails_host;
     return ICELK_OK;
 }
 

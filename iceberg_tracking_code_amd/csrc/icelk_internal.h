@@ -182,7 +182,42 @@ struct DetectScratch {
     float* aemax;
     unsigned* fmax_key;      // [0] largest lower bound of the frame, [1] entries in aties
     unsigned* aties;         // pixels (y << 16 | x) whose neighbourhood the exact pass must look at; 0x80000000 | tile: whole tile
+    // device-driven tail (k_tail.hip): control words (TailCtl), response-bin histogram / offsets / cursors, histogram of the launch order
+    int* tail_ctl;
+    int* tail_resp;
+    int* tail_bins;
 };
+// k_tail.hip: words of DetectScratch::tail_ctl
+enum TailCtl { TC_TICKET_GATHER = 0, TC_TICKET_RANK, TC_TICKET_ORDER, TC_NOUT, TC_STATUS, TC_CAND, TC_ACC, TC_UNDECIDED, TC_PRUNED, TC_WORDS_ = 16 };
+// verdict of the device-driven tail (h_counts[5]): anything but TAIL_OK leaves the tail to the host (detect_finish)
+enum TailStatus { TAIL_OK = 0, TAIL_UNDECIDED = 1, TAIL_PRUNED_SHORT = 2, TAIL_OVERFLOW = 3, TAIL_SKEWED = 4 };
+constexpr int kTailOrderBins = 8192;
+constexpr int kTailRespBins = 4096;
+struct TailOrderGeo {   // cells of the launch order (k_tracks.hip k_seg_order): bin 0 = border features
+    int cw_shift, ch_shift, cells_x, ncells, w, h, border_px;
+};
+struct TailReset {      // the counters a detection leaves zeroed for the next one of its set (k_corners.hip k_detect_reset)
+    int* cell_count;
+    int* cell_fill;
+    int ncell;
+    int* chunk_tot;
+    int* undecided;
+    int* acc_count;
+    int* cand_count;
+    unsigned* key_hist;
+    unsigned* prune_key;
+    int scan_chunk, chunk_stride, key_bins;
+};
+TailOrderGeo tail_order_geometry(int w, int h, int border_px);
+size_t tail_resp_words();
+TailReset tail_reset_of(DetectScratch& D, int ncell);
+// the accepted candidates -> D.acc (what k_gather_accepted does) + their response-bin histogram, bin offsets and the verdict
+void launch_tail_gather(hipStream_t s, DetectScratch& D, int ncell, double quality, int undecided_index, int max_corners,
+                        int cap, int force_status);
+// rank + corner tables of the new segment + launch order + counter reset + counts to the host, all from device-side counts
+void launch_tail_device(hipStream_t s, DetectScratch& D, double quality, float* seg_xy, uint8_t* seg_alive, float* seg_tracks,
+                        int max_vert, int* order, int* order_border, const TailOrderGeo& geo, const TailReset& rs,
+                        int* host_counts, int counts_seq_word, int seq);
 void launch_min_eig(hipStream_t s, const Level& img, int block_size, float* eig, const uint8_t* mask,
                     int mask_pitch, unsigned* max_key, int variant = 0);
 bool fused_block_size(int bs);
@@ -209,8 +244,9 @@ void launch_flatten(hipStream_t s, DetectScratch& D, double quality);
 // D.undecided[suppress_launch_count()-1] != 0 afterwards means the relaxation has not converged yet: call
 // continue_min_distance and look again.
 // prune_want > 0: only the ~prune_want strongest candidates take part (valid iff the accepted ones reach maxCorners)
+// no_gather: the caller gathers the accepted candidates itself (launch_tail_gather: the device-driven tail)
 void launch_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double min_distance, double quality,
-                         int prune_want);
+                         int prune_want, bool no_gather = false);
 void continue_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double min_distance);
 int suppress_launch_count();
 size_t sort_tmp_bytes(int n);

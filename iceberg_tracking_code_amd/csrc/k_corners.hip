@@ -1294,8 +1294,26 @@ static void gather_launch(hipStream_t s, DetectScratch& D, int ncell)
                        D.acc_count);
 }
 
+TailReset tail_reset_of(DetectScratch& D, int ncell)
+{
+    TailReset r{};
+    r.cell_count = D.cell_count;
+    r.cell_fill = D.cell_fill;
+    r.ncell = ncell;
+    r.chunk_tot = D.chunk_tot;
+    r.undecided = D.undecided;
+    r.acc_count = D.acc_count;
+    r.cand_count = D.cand_count;
+    r.key_hist = D.key_hist;
+    r.prune_key = D.prune_key;
+    r.scan_chunk = SCAN_CHUNK;
+    r.chunk_stride = CHUNK_TOT_STRIDE;
+    r.key_bins = KEY_BINS;
+    return r;
+}
+
 void launch_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double min_distance, double quality,
-                         int prune_want)
+                         int prune_want, bool no_gather)
 {
     const int cell = (int)lrint(min_distance);
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
@@ -1311,7 +1329,7 @@ void launch_min_distance(hipStream_t s, DetectScratch& D, int w, int h, double m
     hipLaunchKernelGGL(k_cell_fill, dim3(4096), dim3(CT), 0, s, src_of(D), D.max_key, quality, D.prune_key, w, cell, gw,
                        D.cell_start, D.cell_fill, D.cell_cand, D.state);
     suppress_launches(s, D, w, h, min_distance);
-    gather_launch(s, D, ncell);
+    if (!no_gather) gather_launch(s, D, ncell);
 }
 
 // more relaxation launches + a fresh gather (only when the first batch left candidates undecided)

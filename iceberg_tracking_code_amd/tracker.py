@@ -82,6 +82,13 @@ class SegmentTracker:
         # how many steps ahead of a detection frame its min-distance stage / its corner candidates may start (`_step`)
         self.begin_ahead, self.prepare_ahead, self.stage_lag = 4, 6, 2
         self.stage_nowait = True  # the host round trip of a detection is taken without waiting (icelk_seg_detect_stage_try)
+        # the step (counted back from the detection frame) at whose end the host WAITS for a detection's counts if they have
+        # not come by themselves.  0: never before the frame itself -- the tail of a detection runs on the device without the
+        # host (k_tail.hip), so adopting it is a look at pinned memory, done right before the switch.  1: at the end of step
+        # d-1, as long as the tail needed the host (ICELK_HOST_TAIL=1: it had to be enqueued a step before it was needed)
+        self.stage_block_at = 1 if os.environ.get("ICELK_HOST_TAIL") else 0
+        if os.environ.get("ICELK_STAGE_BLOCK_AT"):     # A/B measurements
+            self.stage_block_at = int(os.environ["ICELK_STAGE_BLOCK_AT"])
         self._resident = False    # inside push_slot
         # callable(first_frame, closed) invoked once per finished segment, when all its pairs have been launched: e.g.
         # ctx.seg_archive(..., closed=closed).  closed=False: the segment is still the current one (the switch follows);
@@ -202,6 +209,14 @@ class SegmentTracker:
         next_slot, next2_slot = slot_of.get(1), slot_of.get(2)
         self._pyr_ahead.discard(slot)
         staged_now = self._staged and self._staged_for == c
+        if detect and ahead and not staged_now and not self._staged and self._det_queue and self._det_queue[0][0] == c \
+                and self._det_queue[0][1] < c:
+            # the detection of this frame was begun steps ago and its tail has run on the device: adopt it now (waits only if
+            # the device is behind)
+            self._staged_n = self.ctx.seg_detect_stage(self.fp["maxCorners"])
+            self._staged, self._staged_for = True, c
+            self._det_queue.pop(0)
+            staged_now = True
         if detect and not staged_now and not (self._det_queue and self._det_queue[0][0] == c):
             # nothing was started ahead for this detection frame: start it now, on its own stream, so that it runs
             # beside the tracker launch below (the reference does them back to back, s1:323-326 then s1:437)
@@ -265,7 +280,7 @@ class SegmentTracker:
                     # without waiting while there is a later step to do it at; the segment is needed at step d
                     # (waiting only at d itself was measured too: the tail of the detection -- sort, corner list, the new
                     # segment's tables -- then starts when the tracker launch already needs it: C3 3 820 -> 3 290 pairs/s)
-                    if d - c <= 1 or not self.stage_nowait:
+                    if d - c <= self.stage_block_at or not self.stage_nowait:
                         n_new = self.ctx.seg_detect_stage(self.fp["maxCorners"])
                     else:
                         n_new = self.ctx.seg_detect_stage_try(self.fp["maxCorners"])

@@ -255,6 +255,12 @@ int icelk_seg_track_len_hint(icelk_t* h, int track_len);
  * backward pass left templates for a successor (diagnostics; tests/test_gpu_api.py uses it to see the reuse engage and
  * refuse: a pair whose first frame is not the frame the templates were built on builds its own). */
 int icelk_seg_template_stats(icelk_t* h, long long* out);
+/* out[0] = segments whose tables were written by the device-driven tail of their detection (k_tail.hip: sort, maxCorners
+ * cut, corner list = the reset `tracks = [[(x, y)] ...]` of s1:440-448, launch order -- all from the device-side counts,
+ * enqueued by icelk_seg_detect_begin; icelk_seg_detect_stage only adopts the verdict), out[1] = segments staged by the
+ * host's tail (min-distance relaxation not converged, a pruned candidate set that fell short of maxCorners,
+ * minDistance < 1, or ICELK_HOST_TAIL=1).  Results are the same either way. */
+int icelk_seg_tail_stats(icelk_t* h, long long* out);
 int icelk_seg_read_closed(icelk_t* h, float* tracks, float* quality, int cap, int max_vertices, int* out_n,
                           int* out_vertices);
 int icelk_seg_archive_closed(icelk_t* h, void* dev_tracks, void* dev_quality, void* dev_count, int cap_rows,

@@ -643,3 +643,48 @@ def test_template_reuse_changes_nothing(synth, monkeypatch, win, levels):
     assert len(a) == len(b) >= 2 and off == (0, 0) and taken >= 4 and left >= taken
     for (fa, ta, qa), (fb, tb, qb) in zip(a, b):
         assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb) and len(ta) > 50
+
+
+@pytest.mark.parametrize("max_corners", [0, 700])
+def test_device_driven_detection_tail_equals_the_hosts(synth, monkeypatch, max_corners):
+    """The tail of a detection that starts a segment (sort of the accepted corners, maxCorners cut, the segment's tables =
+    the reset of s1:440-448, launch order) runs on the device from the device-side counts (k_tail.hip); the host adopts
+    its verdict.  Same segments as with the host's tail (ICELK_HOST_TAIL=1: round 3's path) and as with the host's tail
+    BEHIND a device verdict of "not valid" (ICELK_TAIL_FORCE_STATUS: the path a non-converged min-distance relaxation or
+    a pruned candidate set that fell short takes), with frames resident and the detector's work spread over the steps
+    before its frame; the statistics say which tail staged the segments."""
+    from iceberg_tracking_code_amd import Context, SegmentTracker
+    w, h, n = 1030, 770, 11
+    frames, _ = synth.sequence(w, h, n, seed=17, max_step_px=2.0)
+    fp = dict(maxCorners=max_corners, qualityLevel=0.007, minDistance=10, blockSize=10)
+    lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
+
+    def run():
+        ctx = Context(w, h, n_slots=n, max_pts=1 << 15)
+        for i, f in enumerate(frames):
+            ctx.upload_gray(i, f)
+        trk = SegmentTracker(w, h, 2, fp, lk, ctx=ctx)
+        out = []
+        for i in range(n):
+            s = trk.push_slot(i, i % 4 == 0, *[i + k if i + k < n else None for k in range(1, 7)])
+            if s is not None:
+                out.append(s)
+        trk.flush()
+        tracks, quality = ctx.seg_read()
+        stats = ctx.seg_tail_stats()
+        trk.close()
+        return out, tracks, quality, stats
+
+    dev, dt, dq, dstat = run()
+    monkeypatch.setenv("ICELK_HOST_TAIL", "1")
+    host, ht, hq, hstat = run()
+    monkeypatch.delenv("ICELK_HOST_TAIL")
+    monkeypatch.setenv("ICELK_TAIL_FORCE_STATUS", "1")
+    forced, ft, fq, fstat = run()
+    assert dstat[0] >= 5 and dstat[1] == 0 and hstat[0] == 0 and hstat[1] == dstat[0] and fstat == hstat
+    assert len(dev) == len(host) == len(forced) == 2
+    for other in (host, forced):
+        for (fa, ta, qa), (fb, tb, qb) in zip(dev, other):
+            assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb)
+            assert len(ta) > (500 if max_corners else 2000)
+    assert np.array_equal(dt, ht) and np.array_equal(dq, hq) and np.array_equal(dt, ft) and np.array_equal(dq, fq)
