@@ -176,8 +176,8 @@ def _cv2_unit(cv2, frames, maxc, cfg):
 
 def cpu_baseline(cfg, motion):
     """the loop body timed on THIS host's cores in the same run -- 1 warm-up + median of 5, at all
-    cores and at 1 thread, on a bounded sample (a full-width band of the frame, features scaled alike), the repo's own C
-    restatement (oracle/, kind "port") always and the reference's cv2 call sequence too where cv2 imports."""
+    cores on the full frame and at 1 thread on a bounded sample (a full-width band of the frame, features scaled alike),
+    the repo's own C restatement (oracle/, kind "port") always and the reference's cv2 call sequence too where cv2 imports."""
     import oracle
     from iceberg_tracking_code_amd import synth
     oracle.build()
@@ -202,13 +202,13 @@ def cpu_baseline(cfg, motion):
                usable_cores=usable_cores(), cv2=probe_cv2(),
                protocol="1 warm-up + median of 5 repeats of [1 detection + %d forward/backward pairs]" % TRACK_LEN)
     all_cores = oracle.set_threads(usable_cores())
-    rows_all = min(h, 750)
+    rows_all = h          # the all-cores leg runs the FULL frame (0.5-2 s per unit at 16 threads); the band is for 1 thread only
     fr, mc = band(rows_all)
     t_all, feats = timed(lambda f, m: _oracle_unit(oracle, f, m, cfg), fr, mc, 5)
     scale = rows_all / float(h)
     out.update(value=TRACK_LEN * scale / t_all, cores=all_cores, tracked_features_per_sec=feats / t_all,
-               sample="a %dx%d band (%.0f%% of the %dx%d frame, %d features) through oracle/icelk_oracle.c, OpenMP over %d "
-                      "threads" % (w, rows_all, 100 * scale, w, h, mc, all_cores))
+               sample="the full %dx%d frame (%d features): 1 detection + %d forward/backward pairs through oracle/icelk_oracle.c, "
+                      "OpenMP over %d threads" % (w, rows_all, mc, TRACK_LEN, all_cores))
     rows_1 = min(h, 250)
     fr1, mc1 = band(rows_1)
     oracle.set_threads(1)
@@ -227,6 +227,38 @@ def cpu_baseline(cfg, motion):
     else:
         out["note"] = "OpenCV unavailable on host -- CPU baseline is the repo's own restatement"
     return out
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU), BEFORE anything in
+    this process has touched the GPU -- no exec of a process that has initialised HIP, the children are plain child
+    processes --, relay rank 0's JSON line and exit non-zero if any rank does.  Equivalent to
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...`."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if env.get("ICELK_BENCH_SHARED_DEVICE"):
+            env["LOCAL_RANK"] = "0"      # rehearsal on one GPU (tools/two_rank.sh): every rank on device 0, RCCL leg skipped
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.buffer.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks exited non-zero: %s\n" % bad)
+        return bad[0][1] if bad[0][1] > 0 else 1
+    return 0
 
 
 def main():
@@ -251,7 +283,20 @@ def main():
                     help="A/B: the last pair of a segment is launched on its own instead of with the first pair of the next")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="start a detection only when its frame is pushed (A/B of the cross-step overlap)")
+    ap.add_argument("--no-archive", action="store_true",
+                    help="A/B: finished segments are not compacted into the device archive inside the timed region "
+                         "(the loop's output, s1:394-395, is then left out of it)")
     args = ap.parse_args()
+    echo_dir = os.environ.get("ICELK_BENCH_SPAWN_ECHO")     # tests/test_host_logic.py: what a spawned rank is handed
+    if echo_dir and "WORLD_SIZE" in os.environ:
+        info = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        info.update(gpus=args.gpus, steps=args.steps, warmup=args.warmup)
+        with open(os.path.join(echo_dir, "rank_%s.json" % info["RANK"]), "w") as f:
+            json.dump(info, f)
+        print(json.dumps(info))
+        sys.exit(int(os.environ.get("ICELK_BENCH_SPAWN_ECHO_FAIL", "0")) if info["RANK"] == "1" else 0)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly one JSON line: gloo / RCCL print banners to file descriptor 1, so everything but that
     # line is sent to stderr
@@ -333,6 +378,24 @@ def main():
     # ahead for the first timed steps -- the timed region is a window of the steady state: K pairs go out inside it
     order = list(range(ring)) if linear else ping_pong(ring, K + W + SegmentTracker.MAX_AHEAD)
     archive = None
+
+    def ring_archive(tracker):
+        """The loop's output (s1:394-395: one `tracks` / `trackquality` pair per finished segment): every finished segment is
+        compacted, in track order, into a ring of archive entries on the device (icelk_seg_archive; what C4 gathers over
+        RCCL at the end) -- inside the timed region."""
+        rows = max_pts if cfg["max_corners"] <= 0 else cfg["max_corners"]
+        n_ring = 8
+        a = dict(tracks=torch.zeros((n_ring, rows, TRACK_LEN + 1, 2), dtype=torch.float32, device="cuda"),
+                 quality=torch.zeros((n_ring, rows, TRACK_LEN), dtype=torch.float32, device="cuda"),
+                 counts=torch.zeros(n_ring, dtype=torch.int32, device="cuda"), n=0, rows=rows, ring=n_ring)
+
+        def on_close_ring(first_frame, closed):
+            s = a["n"] % a["ring"]
+            ctx.seg_archive(a["tracks"][s].data_ptr(), a["quality"][s].data_ptr(), a["counts"][s:s + 1].data_ptr(), a["rows"],
+                            closed=closed)
+            a["n"] += 1
+        tracker.on_close = on_close_ring
+        return a
     if linear:
         # warm-up on the W frames before the rank's block with a tracker of its own that starts nothing ahead of time:
         # the timed tracker begins with a clean handle (no detection in flight, no staged segment)
@@ -354,10 +417,14 @@ def main():
                                     closed=closed)
                     archive["n"] = s + 1
             tracker.on_close = on_close
+        elif not args.no_archive:
+            archive = ring_archive(tracker)
         timed_order = order[W:]
         t_first, pushes = 0, K + 1    # the first push of a fresh tracker only detects: K + 1 frames = K frame pairs
     else:
         tracker = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx, lookahead=not args.no_lookahead, pair_launch=not args.no_pair_launch)
+        if not args.no_archive:
+            archive = ring_archive(tracker)
         run_resident(tracker, order, 0, W)
         timed_order = order
         t_first, pushes = W, K        # steady state: every push tracks one pair
@@ -370,6 +437,8 @@ def main():
     # records per kernel on the detector's streams and 7 % of the throughput: --time-all-kernels
     ctx.prof_enable(0 if args.no_kernel_timing else (1 if args.time_all_kernels else 2))
     barrier()
+    archived0 = archive["n"] if archive else 0
+    pairs0 = tracker.pairs_launched
     t0 = time.perf_counter()
     run_resident(tracker, timed_order, t_first, pushes)
     tracker.flush()    # a last pair held back for a joint launch goes out (and is archived) inside the timed region
@@ -377,15 +446,25 @@ def main():
     t1 = time.perf_counter()
     ctx.prof_enable(False)
     prof = ctx.prof_table()
+    archived = (archive["n"] - archived0) if archive else 0
+    archiving = archive is not None
+    pairs_by_tracker = tracker.pairs_launched - pairs0
     consumed = tracker.abort()      # what was started ahead for frames beyond the timed steps is abandoned (it has run)
     n_live, tracked1 = tracker.live()
     elapsed = t1 - t0
     tracked = tracked1 - tracked0
     # frame pairs whose tracker launch lies inside the timed region (a joint launch carries two)
-    pairs_launched = None
+    # counted by the tracker itself (the same quantity with and without --no-kernel-timing); the HIP-event table of the
+    # tracker launches must agree where it exists
+    pairs_launched = pairs_by_tracker
+    pairs_by_events = None
     if not args.no_kernel_timing:
-        pairs_launched = (prof.get("lk_fb", {}).get("launches", 0) + 2 * prof.get("lk_fb_pair", {}).get("launches", 0))
-    pairs_timed = K if pairs_launched is None else pairs_launched
+        pairs_by_events = (prof.get("lk_fb", {}).get("launches", 0) + 2 * prof.get("lk_fb_pair", {}).get("launches", 0))
+    pairs_timed = pairs_launched
+    # segments that closed inside the timed region: detection frames among the timed steps (the first frame of a fresh
+    # tracker only starts a segment)
+    first_counter = 0 if linear else W
+    segments_expected = len([c for c in range(first_counter, first_counter + pushes) if c % TRACK_LEN == 0 and c > 0])
 
     # ---- the same kernels once more, each ALONE on the device (outside the timed region): inside the pipeline their
     # HIP-event durations include waiting for wave slots beside the tracker launch ------------------------------------------
@@ -485,13 +564,17 @@ def main():
 
     # ---- the collectives of the path: per-segment track counts and the padded track tables, over RCCL -------------------
     tracked_all, gather = [tracked], None
+    if cname != "c4":
+        archive_ring, archive = archive, None     # the gathers below are C4's: one archive entry per segment of the block
+    else:
+        archive_ring = archive
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         seg_counts = archive["counts"][:archive["n"]].cpu().numpy().tolist() if archive else [tracked]
         share = os.environ.get("ICELK_BENCH_SHARED_DEVICE")   # tools/two_rank.sh: both ranks on one GPU, RCCL cannot form
-        ok, err, backend = True, "", "rccl"
+        ok, err, backend, rccl_ranks = True, "", "rccl", None
         g0 = time.perf_counter()
         res_counts, res_tables = None, None
         if share:
@@ -499,6 +582,7 @@ def main():
         else:
             try:
                 rccl = dist.new_group(backend="nccl")     # RCCL over xGMI
+                rccl_ranks = int(dist.get_world_size(rccl))
                 res_counts = sharding.gather_counts(seg_counts + [tracked], dist, device="cuda", group=rccl)
                 if archive:
                     res_tables = sharding.gather_tables(archive["tracks"][:max(archive["n"], 1)], archive["counts"][:max(archive["n"], 1)],
@@ -523,7 +607,8 @@ def main():
         per_rank = len(seg_counts) + 1
         rc = np.asarray(res_counts, np.int64).reshape(world, per_rank) if len(res_counts) == world * per_rank else None
         tracked_all = rc[:, -1].tolist() if rc is not None else [tracked]
-        gather = dict(backend=backend, ok=bool(all_ok or share), seconds=g1 - g0, error=err or None,
+        gather = dict(backend=backend, ok=bool(all_ok or share), seconds=g1 - g0, error=err or None, rccl_ranks=rccl_ranks,
+                      segments_gathered=len(res_tables) if res_tables is not None else None,
                       segments=int(sum(len(seg_counts) for _ in range(world))) if archive else 0,
                       tracks_in_tables=int(sum(n for _, n in res_tables)) if res_tables is not None else None,
                       table_bytes_per_rank=int(archive["tracks"][:max(archive["n"], 1)].numel() * 4) if archive else 0)
@@ -541,6 +626,11 @@ def main():
             "tracked_features_per_sec": feats_per_s,
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / max(pairs_timed, 1),
             "pairs_launched_in_timed_region": pairs_launched, "pairs_expected": K,
+            "pairs_launched_by_hip_events": pairs_by_events,
+            "pairs_mismatch": bool(pairs_launched != K or (pairs_by_events is not None and pairs_by_events != pairs_launched)),
+            "segments_archived_in_timed_region": archived if archiving else None, "segments_expected": segments_expected,
+            "archive": ("every finished segment compacted on the device inside the timed region (icelk_seg_archive: tracks + "
+                        "trackquality of s1:394-395)" if archiving else "off (--no-archive)"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32/f32",
             "data": "synthetic",
             "config": {"workload": cfg["name"], "width": w, "height": h, "max_corners": cfg["max_corners"],

@@ -76,6 +76,7 @@ SIGNATURES = {
     "icelk_seg_track_len_hint": (C.c_int, [handle_p, C.c_int]),
     "icelk_seg_template_stats": (C.c_int, [handle_p, C.POINTER(C.c_longlong)]),
     "icelk_seg_tail_stats": (C.c_int, [handle_p, C.POINTER(C.c_longlong)]),
+    "icelk_seg_template_info": (C.c_int, [handle_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), i32p]),
     "icelk_seg_read_closed": (C.c_int, [handle_p, f32p, f32p, C.c_int, C.c_int, i32p, i32p]),
     "icelk_seg_archive_closed": (C.c_int, [handle_p, vp, vp, vp, C.c_int, i32p]),
     "icelk_seg_live": (C.c_int, [handle_p, i32p, i64p]),

@@ -324,6 +324,12 @@ class Context:
         self._ck(self._lib.icelk_seg_template_stats(self._h, out))
         return int(out[0]), int(out[1])
 
+    def seg_template_info(self):
+        """(bytes of one template table, tracks it has room for, state: 0 in use / 1 switched off / 2 allocation failed)."""
+        by, rows, st = C.c_longlong(0), C.c_longlong(0), C.c_int(0)
+        self._ck(self._lib.icelk_seg_template_info(self._h, C.byref(by), C.byref(rows), C.byref(st)))
+        return int(by.value), int(rows.value), int(st.value)
+
     def seg_tail_stats(self):
         """(segments staged by the device-driven detection tail, segments staged by the host's tail) -- diagnostics."""
         out = (C.c_longlong * 2)()

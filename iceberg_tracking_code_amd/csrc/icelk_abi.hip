@@ -151,8 +151,11 @@ struct Ctx {
     struct {
         void* buf[2] = {nullptr, nullptr};
         size_t bytes = 0;          // per table
+        size_t row_bytes = 0;      // bytes per track the tables were laid out for (levels x quads x 64 lanes x 16 B)
+        size_t budget = (size_t)8 << 30;   // both tables together (ICELK_TEMPLATE_BUDGET_MB)
         int quads = 0, levels = 0;
         bool off = false;          // ICELK_NO_TEMPLATE_REUSE, or the tables could not be allocated
+        bool failed = false;       // ... the latter
         long long taken = 0, left = 0;   // pairs whose forward pass took templates / whose backward pass left them
     } tmpl;
     int track_len_hint = 0;        // icelk_seg_track_len_hint: pairs per segment (0: unknown -- every pair leaves templates)
@@ -1303,36 +1306,44 @@ static LKJob seg_job(Ctx* c, int set, const Slot& s0, const Slot& s1, const LKPa
     // (the templates were built on the frame and pyramid that sat in the pair's second slot: they serve the next pair
     // only if that very frame is now its first)
     const int slot0 = (int)(&s0 - c->slots.data()), slot1 = (int)(&s1 - c->slots.data());
-    const bool take = quads > 0 && S.tmpl_for == S.vert && S.tmpl_key == key && S.tmpl_slot == slot0 &&
-                      S.tmpl_gen == s0.gen;
+    bool take = quads > 0 && S.tmpl_for == S.vert && S.tmpl_key == key && S.tmpl_slot == slot0 && S.tmpl_gen == s0.gen;
     S.tmpl_for = -1;
     if (quads > 0 && !c->tmpl.off) {
         const bool last = c->track_len_hint > 0 && S.vert >= c->track_len_hint;
-        // sized by the tracks of the segments seen, not by max_pts (a handle made for 2^18 points would set 2 x 4 GB aside
-        // at 21x21): rows for this segment now, rounded up generously when the tables have to grow
         const size_t per_row = (size_t)(P.top_level + 1) * ((size_t)quads * 64) * 16;
         const size_t need = (size_t)std::max(S.upper, 1) * per_row;
-        if (!last && need > c->tmpl.bytes) {   // (then nothing was left for this key: `take` is false)
-            size_t rows = 16384;
-            while (rows < (size_t)S.upper) rows *= 2;
-            rows = std::min(rows, (size_t)std::max(c->max_pts, 1));
-            const size_t alloc = std::max(rows * per_row, need);
+        // The two tables are sized ONCE per row geometry (window, levels), for max_pts rows within the handle's template
+        // budget (ICELK_TEMPLATE_BUDGET_MB, default 8 GB for both; never more than half of what the device has free) --
+        // not by the segments seen: growing them meant hipFree + hipMalloc in the middle of the frame loop (a device-wide
+        // synchronisation) while a pair held back by icelk_seg_track_defer could still point into the freed table.  A
+        // segment with more tracks than rows fit simply takes no part.  Another row geometry (other LK parameters) is the
+        // one case that allocates again: a waiting pair goes out first, and hipFree waits for whatever is in flight.
+        if (!last && c->tmpl.row_bytes != per_row) {
+            if (c->defer.pending) (void)flush_deferred(c);   // its job carries pointers into the tables about to go
             for (void*& b : c->tmpl.buf) {
                 if (b) hipFree(b);
                 b = nullptr;
             }
             c->tmpl.bytes = 0;
+            c->tmpl.row_bytes = per_row;
             for (Ctx::SegBuf& o : c->sb) o.tmpl_for = -1;
-            if (hipMalloc(&c->tmpl.buf[0], alloc) == hipSuccess && hipMalloc(&c->tmpl.buf[1], alloc) == hipSuccess) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+            const size_t budget = std::min(c->tmpl.budget / 2, free_b / 4);   // per table
+            const size_t rows = std::min((size_t)std::max(c->max_pts, 1), budget / per_row);
+            const size_t alloc = rows * per_row;
+            if (rows > 0 && hipMalloc(&c->tmpl.buf[0], alloc) == hipSuccess && hipMalloc(&c->tmpl.buf[1], alloc) == hipSuccess) {
                 c->tmpl.bytes = alloc;
             } else {
                 (void)hipGetLastError();
                 if (c->tmpl.buf[0]) hipFree(c->tmpl.buf[0]);
                 c->tmpl.buf[0] = c->tmpl.buf[1] = nullptr;
-                c->tmpl.off = true;   // no room: every pair builds its own templates, as before
+                c->tmpl.off = true;   // no room: every pair builds its own templates, as before (icelk_seg_template_info says so)
+                c->tmpl.failed = true;
             }
         }
-        if (c->tmpl.bytes >= need) {
+        if (c->tmpl.row_bytes != per_row) take = false;   // (the last pair of a segment with another row geometry)
+        if (c->tmpl.bytes >= need && c->tmpl.row_bytes == per_row) {
             B.tmpl_levels = P.top_level + 1;
             if (take) {
                 B.tmpl_in = c->tmpl.buf[set & 1];
@@ -1669,6 +1680,7 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
     c->pyr_per_level = getenv("ICELK_PYR_PER_LEVEL") != nullptr;
     c->pyr_ahead_one_wave = getenv("ICELK_PYR_AHEAD_WIDE") == nullptr;
     c->tmpl.off = getenv("ICELK_NO_TEMPLATE_REUSE") != nullptr;
+    if (const char* tb = getenv("ICELK_TEMPLATE_BUDGET_MB")) c->tmpl.budget = (size_t)std::max(atoll(tb), 0LL) << 20;
     c->host_tail = getenv("ICELK_HOST_TAIL") != nullptr;
     if (const char* fs = getenv("ICELK_TAIL_FORCE_STATUS")) c->tail_force_status = std::min(std::max(atoi(fs), 0), 4);
     if (!c->border_first) c->border_px = 0;
@@ -2507,6 +2519,16 @@ int icelk_seg_template_stats(icelk_t* h, long long* out)
     if (!h || !out) return ICELK_EARG;
     out[0] = C(h)->tmpl.taken;
     out[1] = C(h)->tmpl.left;
+    return ICELK_OK;
+}
+
+int icelk_seg_template_info(icelk_t* h, long long* bytes_per_table, long long* rows, int* state)
+{
+    if (!h) return ICELK_EARG;
+    Ctx* c = C(h);
+    if (bytes_per_table) *bytes_per_table = (long long)c->tmpl.bytes;
+    if (rows) *rows = c->tmpl.row_bytes ? (long long)(c->tmpl.bytes / c->tmpl.row_bytes) : 0;
+    if (state) *state = c->tmpl.failed ? 2 : (c->tmpl.off ? 1 : 0);
     return ICELK_OK;
 }
 

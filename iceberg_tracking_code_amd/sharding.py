@@ -40,10 +40,10 @@ def gather_counts(local_counts, dist=None, device=None, group=None):
     all_gather suffices; messages are a few hundred bytes, i.e. latency bound on any fabric.
     """
     local = np.asarray(local_counts, np.int64).ravel()
-    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and group is None):
+    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local.copy()
     import torch
-    world = dist.get_world_size()
+    world = dist.get_world_size(group)
     n = torch.tensor([local.size], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
@@ -67,18 +67,19 @@ def gather_tables(tracks, counts, dist=None, group=None, root=0):
     buffers were sized for, and not to every rank: at BASELINE.json configs[3]'s length (1 350 segments of 10 000 x 3 x 2
     floats per rank) an all_gather of the padded tables would put 8 x 324 MB on every GPU and copy all of it to every
     host.  With backend "nccl" both are RCCL over xGMI, and the only exchange of a sharded run.
-    Returns on `root` a list with one (first_rows, n) numpy pair per segment of the whole sequence
-    [(tracks[:n], n), ...]; on the other ranks None.
+    `root` is a GLOBAL rank (as torch.distributed.gather's dst) and must belong to `group`; the sizes follow the group, so
+    a group that is not the whole world works.  Returns on `root` a list with one (first_rows, n) numpy pair per segment of
+    the group's part of the sequence [(tracks[:n], n), ...], in group-rank order; on the other ranks None.
     """
     import torch
     S = int(tracks.shape[0])
-    world = 1 if dist is None or not dist.is_initialized() else dist.get_world_size()
+    world = 1 if dist is None or not dist.is_initialized() else dist.get_world_size(group)
     if world == 1:
         c = counts.cpu().numpy().astype(np.int64)
         t = tracks.cpu().numpy()
         return [(t[s, :c[s]].copy(), int(c[s])) for s in range(S)]
     dev = tracks.device
-    rank = dist.get_rank()
+    rank = dist.get_rank()            # global ranks: `root` and gather's dst are global, also inside a sub-group
     n_seg = torch.tensor([S], dtype=torch.int64, device=dev)
     all_seg = [torch.zeros_like(n_seg) for _ in range(world)]
     dist.all_gather(all_seg, n_seg, group=group)

@@ -102,6 +102,7 @@ class SegmentTracker:
         self._staged = False      # a new segment waits in the spare set for the switch
         self._staged_for = None   # ... the detection frame it belongs to
         self._staged_n = 0
+        self.pairs_launched = 0   # frame pairs handed to the tracker kernels so far (a joint launch carries two)
 
     # -- frame sources --------------------------------------------------------------------------
     def _next_slot(self):
@@ -237,6 +238,7 @@ class SegmentTracker:
                 self.ctx.seg_track_defer(prev, slot, *lk_tail)
                 self.ctx.seg_switch()
                 self.ctx.seg_track(slot, next_slot, *lk_tail, wait=False)
+                self.pairs_launched += 2
                 self._advanced, self._advanced_slot = True, next_slot
                 if self.on_close is not None:
                     self.on_close(self.seg_first, True)
@@ -245,6 +247,7 @@ class SegmentTracker:
                 self.seg_first = c
             else:
                 self.ctx.seg_track(prev, slot, *lk_tail, wait=False)
+                self.pairs_launched += 1
         if self.lookahead:
             # pyramids of the following frames, on the copy stream, in the shadow of the tracker launch above (two ahead
             # when a joint launch may need frame c+2 at step c+1)

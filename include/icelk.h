@@ -255,6 +255,12 @@ int icelk_seg_track_len_hint(icelk_t* h, int track_len);
  * backward pass left templates for a successor (diagnostics; tests/test_gpu_api.py uses it to see the reuse engage and
  * refuse: a pair whose first frame is not the frame the templates were built on builds its own). */
 int icelk_seg_template_stats(icelk_t* h, long long* out);
+/* The template tables behind icelk_seg_track_len_hint: bytes of ONE of the two tables, the tracks (rows) it has room for,
+ * and state 0 = in use (or not needed yet), 1 = switched off (ICELK_NO_TEMPLATE_REUSE), 2 = off because the allocation
+ * failed.  They are allocated once per row geometry (window, pyramid levels) at the first pair that can use them, for
+ * max_pts rows within ICELK_TEMPLATE_BUDGET_MB (default 8192 for both tables; at most half of the free device memory); a
+ * segment with more tracks than rows builds its own templates. */
+int icelk_seg_template_info(icelk_t* h, long long* bytes_per_table, long long* rows, int* state);
 /* out[0] = segments whose tables were written by the device-driven tail of their detection (k_tail.hip: sort, maxCorners
  * cut, corner list = the reset `tracks = [[(x, y)] ...]` of s1:440-448, launch order -- all from the device-side counts,
  * enqueued by icelk_seg_detect_begin; icelk_seg_detect_stage only adopts the verdict), out[1] = segments staged by the

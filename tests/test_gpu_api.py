@@ -688,3 +688,53 @@ def test_device_driven_detection_tail_equals_the_hosts(synth, monkeypatch, max_c
             assert fa == fb and np.array_equal(ta, tb) and np.array_equal(qa, qb)
             assert len(ta) > (500 if max_corners else 2000)
     assert np.array_equal(dt, ht) and np.array_equal(dq, hq) and np.array_equal(dt, ft) and np.array_equal(dq, fq)
+
+
+@pytest.mark.parametrize("budget_mb", [None, 64])
+def test_template_tables_survive_a_segment_that_outgrows_the_one_before(synth, monkeypatch, budget_mb):
+    """The last pair of a ~2 000-track segment waits (icelk_seg_track_defer) while the next segment, with more than 16 384
+    tracks, is staged and switched to; the joint launch then carries both.  Round 3 grew the template tables at that
+    moment -- hipFree + hipMalloc under the waiting pair's pointers.  Now they are laid out once, for max_pts rows within
+    the budget (or fewer: with 64 MB the big segment does not fit and builds its own templates); either way tracks and
+    qualities are those of a handle that never reuses a template."""
+    from iceberg_tracking_code_amd import Context
+    w, h = 1600, 1200
+    frames, _ = synth.sequence(w, h, 4, seed=29, max_step_px=2.0)
+    lk = dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01))
+    small = (2000, 0.007, 10, False, 10)
+    big = (30000, 0.0005, 3, False, 3)
+
+    def run():
+        ctx = Context(w, h, n_slots=4, max_pts=1 << 16)
+        for i, f in enumerate(frames):
+            ctx.upload_gray(i, f)
+        ctx.seg_track_len_hint(2)
+        n_small = ctx.seg_detect(0, *small)
+        ctx.seg_track(0, 1, wait=False, **lk)          # leaves templates
+        ctx.seg_detect_begin(2, *big)
+        ctx.seg_track_defer(1, 2, **lk)                # the last pair of the small segment waits ...
+        n_big = ctx.seg_detect_stage(big[0])
+        ctx.seg_switch()
+        ctx.seg_track(2, 3, wait=False, **lk)          # ... and goes out with the first pair of the big one
+        ta, qa = ctx.seg_read(closed=True)
+        tb, qb = ctx.seg_read()
+        info = ctx.seg_template_info()
+        stats = ctx.seg_template_stats()
+        ctx.close()
+        return n_small, n_big, ta, qa, tb, qb, info, stats
+
+    if budget_mb is not None:
+        monkeypatch.setenv("ICELK_TEMPLATE_BUDGET_MB", str(budget_mb))
+    a = run()
+    monkeypatch.setenv("ICELK_NO_TEMPLATE_REUSE", "1")
+    b = run()
+    assert a[0] == b[0] == 2000 and a[1] == b[1] == 30000
+    for k in (2, 3, 4, 5):
+        assert np.array_equal(a[k], b[k])
+    assert len(a[2]) > 1000 and len(a[4]) > 10000 and a[2].shape[1] == 3 and a[4].shape[1] == 2
+    by, rows, state = a[6]
+    assert state == 0 and b[6][2] == 1 and a[7][0] >= 1       # the small segment's second pair took templates
+    if budget_mb is None:
+        assert rows == 1 << 16
+    else:
+        assert 0 < rows < a[1] and by <= budget_mb << 19

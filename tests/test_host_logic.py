@@ -123,3 +123,28 @@ def test_bench_helpers():
     # 18.7 MB per LK call at C2 (N = 10 000, 21x21, maxLevel 3), 19.7 MB pyramid per frame
     assert abs(bench.lk_algorithmic_bytes(4000, 3000, (21, 21), 3, 10000) / 1e6 - 18.7) < 0.2
     assert abs(bench.pyramid_algorithmic_bytes(4000, 3000, 3) / 1e6 - 19.7) < 0.1
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` as the driver invokes it (no launcher, no WORLD_SIZE): the parent starts N child processes
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set before anything touches a GPU, relays rank 0's line and passes a
+    failing rank's exit code on.  (Echo mode: the children report what they were handed and exit before importing torch.)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["ICELK_BENCH_SPAWN_ECHO"] = str(tmp_path)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "8", "--warmup", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["RANK"] == "0" and line["WORLD_SIZE"] == "3" and line["gpus"] == 3 and line["steps"] == 8
+    ranks = [json.load(open(tmp_path / ("rank_%d.json" % r))) for r in range(3)]
+    assert [r["RANK"] for r in ranks] == ["0", "1", "2"] and [r["LOCAL_RANK"] for r in ranks] == ["0", "1", "2"]
+    assert len({r["MASTER_PORT"] for r in ranks}) == 1 and all(r["MASTER_ADDR"] == "127.0.0.1" for r in ranks)
+    env["ICELK_BENCH_SPAWN_ECHO_FAIL"] = "7"
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 7 and "ranks exited non-zero" in out.stderr
+    # one rank per GPU of a shared device (tools/two_rank.sh): every rank is handed device 0
+    env.pop("ICELK_BENCH_SPAWN_ECHO_FAIL")
+    env["ICELK_BENCH_SHARED_DEVICE"] = "1"
+    subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+    assert [json.load(open(tmp_path / ("rank_%d.json" % r)))["LOCAL_RANK"] for r in range(3)] == ["0", "0", "0"]
