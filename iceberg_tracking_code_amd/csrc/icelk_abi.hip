@@ -966,7 +966,7 @@ static int detect_prepare(Ctx* c, int slot, int use_mask, int block_size)
     const double prep_quality = c->prep_quality;
     {
         ProfScope p(c, K_EIG, es);
-        launch_candidates(es, T, s.lv[0], block_size, mask, c->mask_pitch, prep_quality, false, nullptr);
+        launch_candidates(es, T, s.lv[0], block_size, mask, c->mask_pitch, prep_quality, false, nullptr, 0, true);
     }
     rc = check_launch(c, "corner candidates (prepared)");
     if (rc) return rc;

@@ -225,8 +225,10 @@ bool fused_block_size(int bs);
 // the candidate buffer behind it is known to be this detection's: it may have been handed on since)
 void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, int mode);
 // K6+K7: local maxima into per-workgroup regions of D.raw (stream order, no host sync)
+// beside_tracker: the launch is expected to share the device with a tracker launch (one-wave workgroups, k_corners.hip)
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
-                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null, int variant = 0);
+                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null, int variant = 0,
+                       bool beside_tracker = false);
 // K6 + K7 in two passes for blockSize 3 / 5 / 7 / 10 (integer bracket of the map, exact arithmetic at the possible maxima
 // only): same regions, counts and max_key as launch_candidates' one-pass kernel.  quality <= 0: no threshold cut.
 bool launch_candidates_fast(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,

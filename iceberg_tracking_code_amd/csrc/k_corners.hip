@@ -395,9 +395,15 @@ __global__ __launch_bounds__(256) void k_eig_nms(const uint8_t* __restrict__ img
 // ------------------------------------------------------------------------------------------------
 constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 
-template <int BS>
+// NT_ = 256: four waves, one row of a batch each in the row-sum phase.  NT_ = 64 (round 4): ONE wave per workgroup -- the
+// strip is 53 outputs wide at blockSize 10 (halo 1.21 in x instead of 1.045), the four rows of a batch are row-summed by
+// 4 x 14 lanes at once, and no barrier ever waits for another wave.  What it is for: a four-wave workgroup of 128 VGPRs
+// finds room beside a tracker launch only where tracker waves retire on all four SIMDs of a CU at the same moment -- it
+// took 200-580 us there for 75 us of work, and since the tail of a detection no longer waits for the host (k_tail.hip)
+// that kernel paced the whole C2 pipeline -- whereas a one-wave workgroup takes the place of ANY single retiring wave.
+template <int BS, int NT_ = 256>
 struct StripCfg {
-    static constexpr int NT = 256;                 // threads = covariance columns
+    static constexpr int NT = NT_;                 // threads = covariance columns
     static constexpr int AN = BS / 2;
     static constexpr int EW = NT - (BS - 1);       // eigenvalue columns
     static constexpr int TW = EW - 2;              // output columns
@@ -415,7 +421,8 @@ struct StripCfg {
     static constexpr int V_BYTES = R * 3 * VP * 8;
     static constexpr int E_BYTES = 8 * NT * 4;
     static constexpr int LDS_BYTES = V_BYTES + E_BYTES;
-    static_assert(EH % R == 0 && NG <= 64 && RX * NG <= NT, "one wave per row of a batch");
+    static_assert(EH % R == 0 && NG <= 64 && RX * NG <= NT + RX - 1, "one wave per row of a batch");
+    static_assert(NT == 256 || (NT == 64 && R * NG <= 64), "one-wave form: the rows of a batch side by side in the wave");
     static_assert(RX * (NG - 1) + RX + BS - 2 < VP, "row tasks stay inside a row of column sums");
     static_assert((VP * 8) % 16 == 0, "16-byte reads of the column sums");
 };
@@ -429,13 +436,13 @@ __device__ __forceinline__ float smooth3(float a, float b, float c, float k0, fl
     return __fadd_rn(__fadd_rn(__fmul_rn(k1, a), __fmul_rn(k0, b)), __fmul_rn(k1, c));
 }
 
-template <int BS, bool FRESH>
+template <int BS, bool FRESH, int NT_ = 256>
 __device__ __forceinline__ void strip_body(const uint8_t* __restrict__ img, int w, int h, int pitch, float k0, float k1,
                                            const uint8_t* __restrict__ mask, int mask_pitch, unsigned* __restrict__ max_key,
                                            unsigned long long* __restrict__ raw, int* __restrict__ blk_count,
                                            float* __restrict__ eig_out, uint8_t* smem, int* s_cnt)
 {
-    using C = StripCfg<BS>;
+    using C = StripCfg<BS, NT_>;
     double* Vb = reinterpret_cast<double*>(smem);                 // [R][3][VP]
     float* Er = reinterpret_cast<float*>(smem + C::V_BYTES);      // [8][NT]
     const int tid = threadIdx.x;
@@ -500,7 +507,8 @@ __device__ __forceinline__ void strip_body(const uint8_t* __restrict__ img, int 
     }
 
     unsigned best = 0;
-    const int wr = tid >> 6, g = tid & 63;
+    // row-sum phase: which row of the batch / which group of RX outputs this thread takes (one-wave form: rows side by side)
+    const int wr = NT_ == 256 ? tid >> 6 : tid / C::NG, g = NT_ == 256 ? tid & 63 : tid % C::NG;
     for (int base = 0; base < C::EH; base += C::UNROLL) {
 #pragma unroll
         for (int j = 0; j < C::UNROLL; j++) {
@@ -518,7 +526,7 @@ __device__ __forceinline__ void strip_body(const uint8_t* __restrict__ img, int 
             if (j % C::R != C::R - 1) continue;
             const int eb = i / C::R;                  // batch: eigenvalue rows eb*R .. eb*R + R-1
             __syncthreads();
-            if (g < C::NG) {
+            if (g < C::NG && wr < C::R) {
                 double Sm[3][C::RX];
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
@@ -584,6 +592,23 @@ __device__ __forceinline__ void strip_body(const uint8_t* __restrict__ img, int 
     publish_max(max_key, best, tid);
     __syncthreads();
     if (tid < C::NSUB) blk_count[bid * C::NSUB + tid] = s_cnt[tid];
+}
+
+template <int BS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(80))) void k_eig_strip1(const uint8_t* __restrict__ img, int w, int h, int pitch, float k0,
+                                                    float k1, const uint8_t* __restrict__ mask, int mask_pitch,
+                                                    unsigned* __restrict__ max_key,
+                                                    unsigned long long* __restrict__ raw, int* __restrict__ blk_count,
+                                                    float* __restrict__ eig_out)
+{
+    using C = StripCfg<BS, 64>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int s_cnt[C::NSUB];
+    const int ys = (int)blockIdx.y * C::SH - 1 - C::AN;
+    if (ys - 1 >= 0 && ys + C::NROWS <= h - 1)
+        strip_body<BS, false, 64>(img, w, h, pitch, k0, k1, mask, mask_pitch, max_key, raw, blk_count, eig_out, smem, s_cnt);
+    else
+        strip_body<BS, true, 64>(img, w, h, pitch, k0, k1, mask, mask_pitch, max_key, raw, blk_count, eig_out, smem, s_cnt);
 }
 
 template <int BS>
@@ -1115,27 +1140,42 @@ void launch_fused(hipStream_t s, const Level& img, float k0, float k1, const uin
 
 template <int BS>
 void launch_strip(hipStream_t s, const Level& img, float k0, float k1, const uint8_t* mask, int mask_pitch,
-                  unsigned* max_key, unsigned long long* raw, int* blk_count, float* eig_out, CandSrc* src)
+                  unsigned* max_key, unsigned long long* raw, int* blk_count, float* eig_out, CandSrc* src, bool one_wave)
 {
-    using C = StripCfg<BS>;
-    dim3 grid((img.w + C::TW - 1) / C::TW, (img.h + C::SH - 1) / C::SH);
-    hipLaunchKernelGGL((k_eig_strip<BS>), grid, dim3(C::NT), C::LDS_BYTES, s, img.ptr, img.w, img.h, img.pitch, k0, k1, mask,
-                       mask_pitch, max_key, raw, blk_count, eig_out);
+    if (one_wave) {
+        using C = StripCfg<BS, 64>;
+        dim3 grid((img.w + C::TW - 1) / C::TW, (img.h + C::SH - 1) / C::SH);
+        hipLaunchKernelGGL((k_eig_strip1<BS>), grid, dim3(C::NT), C::LDS_BYTES, s, img.ptr, img.w, img.h, img.pitch, k0, k1, mask,
+                           mask_pitch, max_key, raw, blk_count, eig_out);
+        src->nblk = (int)(grid.x * grid.y) * C::NSUB;
+        src->region = C::TW * C::SUB;
+    } else {
+        using C = StripCfg<BS>;
+        dim3 grid((img.w + C::TW - 1) / C::TW, (img.h + C::SH - 1) / C::SH);
+        hipLaunchKernelGGL((k_eig_strip<BS>), grid, dim3(C::NT), C::LDS_BYTES, s, img.ptr, img.w, img.h, img.pitch, k0, k1, mask,
+                           mask_pitch, max_key, raw, blk_count, eig_out);
+        src->nblk = (int)(grid.x * grid.y) * C::NSUB;
+        src->region = C::TW * C::SUB;
+    }
     src->keys = raw;
     src->blk_count = blk_count;
-    src->nblk = (int)(grid.x * grid.y) * C::NSUB;
-    src->region = C::TW * C::SUB;
 }
 
 // regions / keys the strip layout needs, whichever blockSize is asked for later
-template <int BS>
-void strip_geometry(int w, int h, size_t* regions, size_t* keys)
+template <int BS, int NT_>
+void strip_geometry1(int w, int h, size_t* regions, size_t* keys)
 {
-    using C = StripCfg<BS>;
+    using C = StripCfg<BS, NT_>;
     const size_t r = (size_t)((w + C::TW - 1) / C::TW) * ((h + C::SH - 1) / C::SH) * C::NSUB;
     const size_t k = r * (size_t)(C::TW * C::SUB);
     *regions = r > *regions ? r : *regions;
     *keys = k > *keys ? k : *keys;
+}
+template <int BS>
+void strip_geometry(int w, int h, size_t* regions, size_t* keys)
+{
+    strip_geometry1<BS, 256>(w, h, regions, keys);
+    strip_geometry1<BS, 64>(w, h, regions, keys);
 }
 size_t strip_regions(int w, int h)
 {
@@ -1219,7 +1259,7 @@ void launch_detect_reset(hipStream_t s, DetectScratch& D, int ncell, int mode)
 
 // Candidate collection (K6+K7) into regions of D.raw (stream order, no host sync).
 void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int block_size, const uint8_t* mask,
-                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null, int variant)
+                       int mask_pitch, double quality, bool use_generic, float* eig_out_or_null, int variant, bool beside_tracker)
 {
     if (variant) use_generic = true;     // the named variants live in the any-blockSize kernel only
     unsigned long long* raw = D.raw;
@@ -1235,11 +1275,16 @@ void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int bl
     if (!use_generic && fused_block_size(block_size) && !tiles) {
         float k0, k1;
         sobel_scale(block_size, &k0, &k1);
+        // ICELK_STRIP_WAVES=4: round 3's four-wave strips everywhere; =1: one-wave strips everywhere; default: one wave for
+        // the corner kernel that runs ahead of its detection, beside a tracker launch (icelk_seg_detect_prepare), four waves
+        // where it runs on its own
+        static const char* sw = getenv("ICELK_STRIP_WAVES");
+        const bool one_wave = sw ? atoi(sw) == 1 : beside_tracker;
         switch (block_size) {
-            case 3: launch_strip<3>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
-            case 5: launch_strip<5>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
-            case 7: launch_strip<7>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
-            default: launch_strip<10>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src); break;
+            case 3: launch_strip<3>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, one_wave); break;
+            case 5: launch_strip<5>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, one_wave); break;
+            case 7: launch_strip<7>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, one_wave); break;
+            default: launch_strip<10>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, one_wave); break;
         }
     } else if (!use_generic && fused_block_size(block_size)) {
         float k0, k1;

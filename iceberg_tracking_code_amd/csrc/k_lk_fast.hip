@@ -227,9 +227,11 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
             template_pixels<WW, WH, 1, 0>(T, ldsI, (uint32_t)uni((int)pack_weights_lo(wi)), (uint32_t)uni((int)pack_weights_hi(wi)),
                                           ix0 & 3, i_inside, ipx, ipy, LI.w, LI.h, trow, tcol, pmask, a11, a12, a22);
             // |Ix*Ix| <= 4080^2 per pixel: 16-lane sums fit int32 while a lane holds <= 8 pixels
-            A11 = sum_to_float(sum_pick<kSmall, 16>(a11)) * FLT_SCALE;
-            A12 = sum_to_float(sum_pick<kSmall, 16>(a12)) * FLT_SCALE;
-            A22 = sum_to_float(sum_pick<kSmall, 16>(a22)) * FLT_SCALE;
+            long long s11, s12, s22;
+            wave_sum3_i64<kSmall ? 16 : 1>(a11, a12, a22, s11, s12, s22);
+            A11 = sum_to_float(s11) * FLT_SCALE;
+            A12 = sum_to_float(s12) * FLT_SCALE;
+            A22 = sum_to_float(s22) * FLT_SCALE;
         }
         if (IO::FITS && tmode == 2) tmpl_store<WW, WH>(T, A11, A12, A22, tio + level * IO::LEVEL, lane);
         float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
@@ -279,8 +281,10 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
             residual_pixels<WW, WH, 1, 0, false>(T, ldsJ, jb, (uint32_t)uni((int)pack_weights_lo(wj)),
                                                  (uint32_t)uni((int)pack_weights_hi(wj)), joff, tlen, b1, b2);
             // |diff*Ix| <= 8160*4080 per pixel: 8-lane sums fit int32 while a lane holds <= 8 pixels
-            const float fb1 = sum_to_float(sum_pick<kSmall, 8>(b1)) * FLT_SCALE;
-            const float fb2 = sum_to_float(sum_pick<kSmall, 8>(b2)) * FLT_SCALE;
+            long long t1, t2;
+            wave_sum2_i64<kSmall ? 8 : 1>(b1, b2, t1, t2);
+            const float fb1 = sum_to_float(t1) * FLT_SCALE;
+            const float fb2 = sum_to_float(t2) * FLT_SCALE;
             const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
             const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
             nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
@@ -289,8 +293,12 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
             // eps^2 (LKParams::eps2_lo / eps2_hi), where the exact form runs
             const float q = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
             bool conv = q < P.eps2_lo;
-            if (!conv && !(q > P.eps2_hi))
+            if (uni(!conv && !(q > P.eps2_hi) ? 1 : 0)) {
+                // a real branch (the values are wave-uniform): flattened, the six double-precision instructions of the exact
+                // form ran in every iteration of every feature for a band that is 2^-19 wide
+                asm volatile("" ::: "memory");
                 conv = __dadd_rn(__dmul_rn((double)dx, (double)dx), __dmul_rn((double)dy, (double)dy)) <= P.eps2;
+            }
             if (conv) break;
             // fabs((double)t) < 0.01 for a float t  <=>  |t| <= 0.01f, the largest float below 0.01
             if (j > 0 && fabsf(__fadd_rn(dx, pdx)) <= 0.01f && fabsf(__fadd_rn(dy, pdy)) <= 0.01f) {

@@ -70,6 +70,86 @@ __device__ __forceinline__ long long wave_sum_grouped(int v)
     return t;
 }
 
+// ---- exact 64-bit wave sums through the DPP network alone (round 4) ------------------------------------------------------
+// wave_sum_grouped reads the 64/G group totals back with v_readlane and adds them on the scalar unit: 8 readlanes and 24
+// scalar instructions (sign extension, add, add-with-carry) per sum at G = 8 -- 28 of the 60 scalar instructions of a
+// tracker iteration, on a scalar unit the CU's four SIMDs share.  Here the upper reduction steps stay in the vector unit as
+// 64-bit adds: v_add_co_u32 / v_addc_co_u32 take DPP operands like any VOP2, so a step is two instructions, the carry
+// travelling through VCC (lanes a step's row mask leaves out execute neither, their VCC bits stay).  Same count of vector
+// instructions as before (3 + 1 + 6 + 2 against 3 + 8), one scalar move pair instead of 24 scalar instructions.
+// Several sums are reduced side by side: a VGPR written by a VALU instruction may be read through DPP two wait states
+// later at the earliest, which the interleaving provides without s_nop (the first step waits explicitly: what the compiler
+// scheduled in front of an asm statement is not known to its hazard recogniser).
+#define ICELK_DPP64_PAIR(LO, HI, CTRL) \
+    "v_add_co_u32_dpp " LO ", vcc, " LO ", " LO " " CTRL "\n\tv_addc_co_u32_dpp " HI ", vcc, " HI ", " HI ", vcc " CTRL "\n\t"
+#define ICELK_DPP_SHR8 "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+#define ICELK_DPP_BC15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define ICELK_DPP_BC31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
+
+// G = lanes whose int32 sum cannot overflow (16, 8 or 1): those steps run in 32 bits
+template <int G>
+__device__ __forceinline__ int dpp_low_steps(int v)
+{
+    static_assert(G == 1 || G == 8 || G == 16, "group size");
+    if (G >= 8) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    }
+    if (G == 16) v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    return v;
+}
+
+__device__ __forceinline__ long long lane63_i64(int lo, int hi)
+{
+    const unsigned l = (unsigned)__builtin_amdgcn_readlane(lo, 63);
+    const int h = __builtin_amdgcn_readlane(hi, 63);
+    return (long long)(((unsigned long long)(unsigned)h << 32) | l);
+}
+
+template <int G>
+__device__ __forceinline__ void wave_sum2_i64(int v0, int v1, long long& s0, long long& s1)
+{
+    int l0 = dpp_low_steps<G>(v0), l1 = dpp_low_steps<G>(v1);
+    int h0 = l0 >> 31, h1 = l1 >> 31;
+    if (G == 1)
+        asm("s_nop 1\n\t"
+            ICELK_DPP64_PAIR("%0", "%1", "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0") ICELK_DPP64_PAIR("%2", "%3", "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+            ICELK_DPP64_PAIR("%0", "%1", "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0") ICELK_DPP64_PAIR("%2", "%3", "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+            ICELK_DPP64_PAIR("%0", "%1", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0") ICELK_DPP64_PAIR("%2", "%3", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+            : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1) : : "vcc");
+    if (G <= 8)
+        asm("s_nop 1\n\t" ICELK_DPP64_PAIR("%0", "%1", ICELK_DPP_SHR8) ICELK_DPP64_PAIR("%2", "%3", ICELK_DPP_SHR8)
+            : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1) : : "vcc");
+    asm("s_nop 1\n\t" ICELK_DPP64_PAIR("%0", "%1", ICELK_DPP_BC15) ICELK_DPP64_PAIR("%2", "%3", ICELK_DPP_BC15)
+        ICELK_DPP64_PAIR("%0", "%1", ICELK_DPP_BC31) ICELK_DPP64_PAIR("%2", "%3", ICELK_DPP_BC31)
+        : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1) : : "vcc");
+    s0 = lane63_i64(l0, h0);
+    s1 = lane63_i64(l1, h1);
+}
+
+template <int G>
+__device__ __forceinline__ void wave_sum3_i64(int v0, int v1, int v2, long long& s0, long long& s1, long long& s2)
+{
+    int l0 = dpp_low_steps<G>(v0), l1 = dpp_low_steps<G>(v1), l2 = dpp_low_steps<G>(v2);
+    int h0 = l0 >> 31, h1 = l1 >> 31, h2 = l2 >> 31;
+    if (G == 1)
+        asm("s_nop 1\n\t"
+            ICELK_DPP64_PAIR("%0", "%1", "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0") ICELK_DPP64_PAIR("%2", "%3", "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0") ICELK_DPP64_PAIR("%4", "%5", "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+            ICELK_DPP64_PAIR("%0", "%1", "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0") ICELK_DPP64_PAIR("%2", "%3", "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0") ICELK_DPP64_PAIR("%4", "%5", "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+            ICELK_DPP64_PAIR("%0", "%1", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0") ICELK_DPP64_PAIR("%2", "%3", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0") ICELK_DPP64_PAIR("%4", "%5", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+            : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2) : : "vcc");
+    if (G <= 8)
+        asm("s_nop 1\n\t" ICELK_DPP64_PAIR("%0", "%1", ICELK_DPP_SHR8) ICELK_DPP64_PAIR("%2", "%3", ICELK_DPP_SHR8) ICELK_DPP64_PAIR("%4", "%5", ICELK_DPP_SHR8)
+            : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2) : : "vcc");
+    asm("s_nop 1\n\t" ICELK_DPP64_PAIR("%0", "%1", ICELK_DPP_BC15) ICELK_DPP64_PAIR("%2", "%3", ICELK_DPP_BC15) ICELK_DPP64_PAIR("%4", "%5", ICELK_DPP_BC15)
+        ICELK_DPP64_PAIR("%0", "%1", ICELK_DPP_BC31) ICELK_DPP64_PAIR("%2", "%3", ICELK_DPP_BC31) ICELK_DPP64_PAIR("%4", "%5", ICELK_DPP_BC31)
+        : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2) : : "vcc");
+    s0 = lane63_i64(l0, h0);
+    s1 = lane63_i64(l1, h1);
+    s2 = lane63_i64(l2, h2);
+}
+
 // correctly rounded int64 -> float for |t| < 2^52, through one exact double
 __device__ __forceinline__ float i64_to_float(long long t)
 {
