@@ -283,6 +283,9 @@ def main():
                     help="A/B: the last pair of a segment is launched on its own instead of with the first pair of the next")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="start a detection only when its frame is pushed (A/B of the cross-step overlap)")
+    ap.add_argument("--lk-sums", type=int, default=0, choices=(0, 1, 2),
+                    help="icelk_set_variant('lk_sums'): 0 = exact sums (default), 1 / 2 = the float-lane order of OpenCV 3.x's SSE2 / "
+                         "4.x's CV_SIMD128 block (DESIGN.md section 2); the rate under a variant is reported, never the headline")
     ap.add_argument("--no-archive", action="store_true",
                     help="A/B: finished segments are not compacted into the device archive inside the timed region "
                          "(the loop's output, s1:394-395, is then left out of it)")
@@ -350,6 +353,8 @@ def main():
     else:
         sh, af = motion_tables(ring, seed + rank, args.motion)
     ctx = Context(w, h, n_slots=ring, max_pts=max_pts, device=local_rank)
+    if args.lk_sums:
+        ctx.set_variant("lk_sums", args.lk_sums)
     probe_info = ctx.stream_probe_info()
     for i in range(ring):
         ctx.synth_frame(i, w, h, int(sh[i, 0]), int(sh[i, 1]), seed if linear else seed + rank, affine=af[i])
@@ -636,7 +641,7 @@ def main():
             "config": {"workload": cfg["name"], "width": w, "height": h, "max_corners": cfg["max_corners"],
                        "win": list(cfg["win"]), "maxLevel": cfg["max_level"], "pyramid_images": top + 1,
                        "criteria": list(cfg["criteria"]), "track_len": TRACK_LEN, "detector": DETECT,
-                       "frames_resident": ring, "source": "HBM-resident",
+                       "frames_resident": ring, "source": "HBM-resident", "lk_sums_variant": args.lk_sums,
                        "motion": "sub-pixel translation (<= 3 px/frame) + affine deformation (<= 0.5 %)" if args.motion == "shear"
                                  else "sub-pixel translation (<= 3 px/frame) only",
                        "sharding": "one sequence of %d frames, segment blocks per rank (sharding.frame_block), no data-path "

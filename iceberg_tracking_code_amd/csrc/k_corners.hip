@@ -1275,11 +1275,13 @@ void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int bl
     if (!use_generic && fused_block_size(block_size) && !tiles) {
         float k0, k1;
         sobel_scale(block_size, &k0, &k1);
-        // ICELK_STRIP_WAVES=4: round 3's four-wave strips everywhere; =1: one-wave strips everywhere; default: one wave for
-        // the corner kernel that runs ahead of its detection, beside a tracker launch (icelk_seg_detect_prepare), four waves
-        // where it runs on its own
+        // ICELK_STRIP_WAVES=1: one-wave strips (k_eig_strip1) for the corner kernel that runs ahead of its detection, beside a
+        // tracker launch (icelk_seg_detect_prepare); =11: everywhere.  Default: round 3's four-wave strips -- measured on one
+        // box, C2 / REF / C5: 5 950 / 766 / 567 pairs/s with one-wave strips against 6 000 / 772 / 569 (the one-wave
+        // workgroups do get onto the CUs at once, and the tracker launch beside them takes 292 us instead of 273)
         static const char* sw = getenv("ICELK_STRIP_WAVES");
-        const bool one_wave = sw ? atoi(sw) == 1 : beside_tracker;
+        const int swv = sw ? atoi(sw) : 0;
+        const bool one_wave = swv == 11 || (swv == 1 && beside_tracker);
         switch (block_size) {
             case 3: launch_strip<3>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, one_wave); break;
             case 5: launch_strip<5>(s, img, k0, k1, mask, mask_pitch, D.max_key, raw, D.blk_count, eig_out_or_null, &g_src, one_wave); break;

@@ -391,8 +391,10 @@ int launch_lk(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKBuffers
     // several-features-per-wave form (k_lk_multi.hip: a third fewer vector instructions per feature, but 2-3 waves per
     // SIMD instead of 4 -- measured slower at 21x21, profiles/r02_lk_kernels.txt; kept as a third statement of the
     // arithmetic and for window sizes / chips where the balance tips)
-    const bool generic = (P.flags & ICELK_FLAG_GENERIC_KERNEL) || P.sum_mode != 0;
-    if ((P.flags & ICELK_FLAG_MULTI_PER_WAVE) && !generic && launch_lk_multi(s, I, J, B, n, P, fb))
+    // (the "lk_sums" variants run in the window-specialised kernel too since round 4 -- k_lk_fast.hip chain_sums --, not in
+    // the several-features-per-wave form)
+    const bool generic = (P.flags & ICELK_FLAG_GENERIC_KERNEL) != 0;
+    if ((P.flags & ICELK_FLAG_MULTI_PER_WAVE) && !generic && !P.sum_mode && launch_lk_multi(s, I, J, B, n, P, fb))
         return ICELK_OK;
     if (!generic && launch_lk_fast(s, I, J, B, n, P, fb)) return ICELK_OK;
     const int npx = P.win_w * P.win_h;

@@ -113,10 +113,71 @@ __device__ __forceinline__ void tmpl_unpack(Template<WW, WH, 1>& T, float& A11, 
 // 2x2 matrices it builds there.  tmode 1: the ones the backward pass of the pair before left there are used instead of
 // building them -- fetched straight into LDS (global_load_lds_dwordx4: no registers, nothing waits), a level ahead:
 // the request for level l-1 goes out when level l has been taken over into registers, and arrives while level l iterates.
+// The "lk_sums" variants (LKParams::sum_mode 1 / 2: A11 .. b2 accumulated in the float lanes of OpenCV's x86 SIMD blocks,
+// oracle/icelk_oracle.c lanes_a_row / lanes_b_px).  Float addition does not associate, so the order IS the result: every
+// pixel's products sit in LDS in raster order (template_pixels / residual_pixels); chain c < 4 of a plane adds the products
+// of the columns x = c (mod 4) below `whole`, row by row, chain 4 those of the columns from `whole` on (the scalar tail of a
+// row), one float addition at a time -- a lane per chain, 5 x planes lanes busy --, and the five chains of a plane are
+// folded the way the blocks fold their lanes.  The same statement as k_lk.hip's lane_chain_sums, here behind the tuned
+// kernel's tiles, templates and packed pixel arithmetic: selecting a variant costs the chains, not the whole kernel.
+template <int WW, int WH, int WHOLE>
+__device__ __forceinline__ void chain_sums_t(const float* fsum, int planes, bool pairwise, float (&out)[3], int lane)
+{
+    constexpr int NPX = WW * WH;
+    // a chain's terms of one window row: columns c, c + 4, ... below WHOLE (NI of them), or the NT columns from WHOLE on.
+    // The terms of RB rows are fetched together (a row at a time each addition waited for its own LDS read: 8 times the
+    // launch time of the default sums at 35x35), then added strictly in raster order; a slot a lane does not have holds
+    // 0.0f, which leaves a sum as it is (no sum here is ever -0).
+    // (terms in flight: 32 where the kernel has registers to spare, 16 for the windows with several segments per lane --
+    // with 32 the 35x35 kernel spilled 525 registers and ran at half the speed of the row-at-a-time form)
+    constexpr int NI = WHOLE / 4, NT = WW - WHOLE, MAXN = NI > NT ? NI : NT, INFL = Cfg<WW, WH>::TPL > 1 ? 16 : 32,
+                  RB = INFL / MAXN > 0 ? INFL / MAXN : 1;
+    __syncthreads();
+    float acc = 0.f;
+    const int p = lane / 5, c = lane - 5 * p;
+    const bool busy = lane < 5 * planes;
+    const int x0 = c < 4 ? c : WHOLE, stride = c < 4 ? 4 : 1, count = busy ? (c < 4 ? NI : NT) : 0;
+    const float* src = fsum + (busy ? p : 0) * NPX + x0;
+#pragma unroll 1
+    for (int y0 = 0; y0 < WH; y0 += RB) {
+        float v[RB][MAXN];
+#pragma unroll
+        for (int r = 0; r < RB; r++)
+#pragma unroll
+            for (int i = 0; i < MAXN; i++) {
+                const bool ok = i < count && y0 + r < WH;
+                v[r][i] = ok ? src[(y0 + r) * WW + i * stride] : 0.f;
+            }
+#pragma unroll
+        for (int r = 0; r < RB; r++)
+#pragma unroll
+            for (int i = 0; i < MAXN; i++) acc = __fadd_rn(acc, v[r][i]);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        if (q >= planes) break;
+        const float q0 = __shfl(acc, 5 * q), q1 = __shfl(acc, 5 * q + 1), q2 = __shfl(acc, 5 * q + 2), q3 = __shfl(acc, 5 * q + 3);
+        const float t = __shfl(acc, 5 * q + 4);
+        out[q] = pairwise ? __fadd_rn(t, __fadd_rn(__fadd_rn(q0, q2), __fadd_rn(q1, q3)))
+                          : __fadd_rn(t, __fadd_rn(__fadd_rn(__fadd_rn(q0, q1), q2), q3));
+    }
+    __syncthreads();
+}
+
+// whole = WW & ~3 (groups of 4 pixels) or WW & ~7 (groups of 8)
+template <int WW, int WH>
+__device__ __forceinline__ void chain_sums(const float* fsum, int planes, int whole, bool pairwise, float (&out)[3], int lane)
+{
+    if (whole == (WW & ~3)) chain_sums_t<WW, WH, (WW & ~3)>(fsum, planes, pairwise, out, lane);
+    else chain_sums_t<WW, WH, (WW & ~7)>(fsum, planes, pairwise, out, lane);
+}
+
+// fsum: LDS room for three planes of WW x WH float products when the launch runs under a "lk_sums" variant, else null
 template <int WW, int WH>
 __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const Pyramid& PJ, float p0x, float p0y,
                                                         const LKParams& P, uint32_t* ldsI, uint32_t* ldsJ, int lane,
-                                                        bool want_err, uint4* __restrict__ tio, int tmode, uint4* tlds)
+                                                        bool want_err, uint4* __restrict__ tio, int tmode, uint4* tlds,
+                                                        float* fsum = nullptr)
 {
     using C = Cfg<WW, WH>;
     using IO = TmplIO<WW, WH>;
@@ -160,6 +221,28 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
         for (int q = 0; q < (S + 1) / 2; q++)
             pmask[k][q] = (2 * q < tlen[k] ? 0xffffu : 0u) | (2 * q + 1 < tlen[k] ? 0xffff0000u : 0u);
     }
+
+    // The window with three segments per lane (35x35) keeps ONE register per segment -- row | column << 8 | pixels
+    // << 16 -- and unpack it where it is used (a few bit-field extracts per level pass / iteration): the unpacked
+    // forms (4 per segment) and the pixel masks (4 per segment) were 24 registers that lived through every loop of a
+    // kernel that spills at 168.  The asm statement keeps the compiler from hoisting the unpacked values back out.
+    // (35x35: 168 VGPRs + 3 spilled + 102 SGPR spills + 16 B of scratch -> 158 VGPRs, 24 SGPR spills, no scratch, at the
+    // same speed.  31x31 -- two segments per lane, 154 VGPRs without a spill -- does not pay for the unpacking: 1 695 us
+    // per pair against 1 645, and held to 128 VGPRs for a fourth wave 1 790; profiles/r04_lk_resources.json)
+    constexpr bool kPackSeg = C::TPL >= 3;
+    uint32_t segp[C::TPL];
+#pragma unroll
+    for (int k = 0; k < C::TPL; k++) segp[k] = (uint32_t)trow[k] | ((uint32_t)tcol[k] << 8) | ((uint32_t)tlen[k] << 16);
+    auto seg_rows_cols = [&](int (&row)[C::TPL], int (&col)[C::TPL], int (&len)[C::TPL]) {
+#pragma unroll
+        for (int k = 0; k < C::TPL; k++) {
+            uint32_t v = segp[k];
+            asm volatile("" : "+v"(v));
+            row[k] = (int)(v & 255u);
+            col[k] = (int)((v >> 8) & 255u);
+            len[k] = (int)(v >> 16);
+        }
+    };
 
     TrackResult Rz;
     Rz.status = 1;
@@ -224,14 +307,32 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
             if (level > 0) fetch(level - 1);
         } else {
             int a11, a12, a22;
+            if constexpr (kPackSeg) {
+                int row_l[C::TPL], col_l[C::TPL], len_l[C::TPL];
+                uint32_t pmask_l[C::TPL][(S + 1) / 2];
+                seg_rows_cols(row_l, col_l, len_l);
+#pragma unroll
+                for (int k = 0; k < C::TPL; k++)
+#pragma unroll
+                    for (int q = 0; q < (S + 1) / 2; q++)
+                        pmask_l[k][q] = (2 * q < len_l[k] ? 0xffffu : 0u) | (2 * q + 1 < len_l[k] ? 0xffff0000u : 0u);
+                template_pixels<WW, WH, 1, 0>(T, ldsI, (uint32_t)uni((int)pack_weights_lo(wi)), (uint32_t)uni((int)pack_weights_hi(wi)),
+                                              ix0 & 3, i_inside, ipx, ipy, LI.w, LI.h, row_l, col_l, pmask_l, a11, a12, a22, fsum, len_l);
+            } else
             template_pixels<WW, WH, 1, 0>(T, ldsI, (uint32_t)uni((int)pack_weights_lo(wi)), (uint32_t)uni((int)pack_weights_hi(wi)),
-                                          ix0 & 3, i_inside, ipx, ipy, LI.w, LI.h, trow, tcol, pmask, a11, a12, a22);
+                                          ix0 & 3, i_inside, ipx, ipy, LI.w, LI.h, trow, tcol, pmask, a11, a12, a22, fsum, tlen);
             // |Ix*Ix| <= 4080^2 per pixel: 16-lane sums fit int32 while a lane holds <= 8 pixels
             long long s11, s12, s22;
             wave_sum3_i64<kSmall ? 16 : 1>(a11, a12, a22, s11, s12, s22);
             A11 = sum_to_float(s11) * FLT_SCALE;
             A12 = sum_to_float(s12) * FLT_SCALE;
             A22 = sum_to_float(s22) * FLT_SCALE;
+            if (fsum) {
+                // 3.x: groups of 4 pixels, lanes folded ((l0+l1)+l2)+l3; 4.x: groups of 8, folded (l0+l2)+(l1+l3)
+                float o[3];
+                chain_sums<WW, WH>(fsum, 3, P.sum_mode == 1 ? (WW & ~3) : (WW & ~7), P.sum_mode == 2, o, lane);
+                A11 = __fmul_rn(o[0], FLT_SCALE); A12 = __fmul_rn(o[1], FLT_SCALE); A22 = __fmul_rn(o[2], FLT_SCALE);
+            }
         }
         if (IO::FITS && tmode == 2) tmpl_store<WW, WH>(T, A11, A12, A22, tio + level * IO::LEVEL, lane);
         float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
@@ -278,13 +379,27 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
             const Weights wj = bilinear_weights(nx - (float)inx, ny - (float)iny);
             const int jb = (iny - jy0) * (C::JPD * 4) + (jx0 & 3) + (inx - jx0);
             int b1, b2;
+            if constexpr (kPackSeg) {
+                int row_l[C::TPL], col_l[C::TPL], len_l[C::TPL], joff_l[C::TPL];
+                seg_rows_cols(row_l, col_l, len_l);
+#pragma unroll
+                for (int k = 0; k < C::TPL; k++) joff_l[k] = row_l[k] * (C::JPD * 4) + col_l[k];
+                residual_pixels<WW, WH, 1, 0, false>(T, ldsJ, jb, (uint32_t)uni((int)pack_weights_lo(wj)),
+                                                     (uint32_t)uni((int)pack_weights_hi(wj)), joff_l, len_l, b1, b2, fsum, row_l, col_l);
+            } else
             residual_pixels<WW, WH, 1, 0, false>(T, ldsJ, jb, (uint32_t)uni((int)pack_weights_lo(wj)),
-                                                 (uint32_t)uni((int)pack_weights_hi(wj)), joff, tlen, b1, b2);
+                                                 (uint32_t)uni((int)pack_weights_hi(wj)), joff, tlen, b1, b2, fsum, trow, tcol);
             // |diff*Ix| <= 8160*4080 per pixel: 8-lane sums fit int32 while a lane holds <= 8 pixels
             long long t1, t2;
             wave_sum2_i64<kSmall ? 8 : 1>(b1, b2, t1, t2);
-            const float fb1 = sum_to_float(t1) * FLT_SCALE;
-            const float fb2 = sum_to_float(t2) * FLT_SCALE;
+            float fb1 = sum_to_float(t1) * FLT_SCALE;
+            float fb2 = sum_to_float(t2) * FLT_SCALE;
+            if (fsum) {
+                // both versions: groups of 8 pixels in 2 x 4 lanes; (q0[k] + q1[k]) pairs = chains (0 + 2) + (1 + 3)
+                float o[3];
+                chain_sums<WW, WH>(fsum, 2, WW & ~7, true, o, lane);
+                fb1 = __fmul_rn(o[0], FLT_SCALE); fb2 = __fmul_rn(o[1], FLT_SCALE);
+            }
             const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
             const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
             nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
@@ -333,6 +448,14 @@ __device__ __forceinline__ TrackResult track_point_fast(const Pyramid& PI, const
             const Weights we = bilinear_weights(qx - (float)iqx, qy - (float)iqy);
             const int jb = (iqy - jy0) * (C::JPD * 4) + (jx0 & 3) + (iqx - jx0);
             int es, unused;
+            if constexpr (kPackSeg) {
+                int row_l[C::TPL], col_l[C::TPL], len_l[C::TPL], joff_l[C::TPL];
+                seg_rows_cols(row_l, col_l, len_l);
+#pragma unroll
+                for (int k = 0; k < C::TPL; k++) joff_l[k] = row_l[k] * (C::JPD * 4) + col_l[k];
+                residual_pixels<WW, WH, 1, 0, true>(T, ldsJ, jb, (uint32_t)uni((int)pack_weights_lo(we)),
+                                                    (uint32_t)uni((int)pack_weights_hi(we)), joff_l, len_l, es, unused);
+            } else
             residual_pixels<WW, WH, 1, 0, true>(T, ldsJ, jb, (uint32_t)uni((int)pack_weights_lo(we)),
                                                 (uint32_t)uni((int)pack_weights_hi(we)), joff, tlen, es, unused);
             const float errval = sum_to_float(sum_pick<kSmall, 8>(es));
@@ -352,12 +475,14 @@ struct LKJobs {
     int g0, g1;
 };
 
-template <int WW, int WH, bool FB>
+template <int WW, int WH, bool FB, bool SM = false>
 __device__ __forceinline__ void lk_fast_body(const LKJobs& JJ, const LKParams& P)
 {
     using C = Cfg<WW, WH>;
     __shared__ uint32_t lds[C::LDS_DW];
-    __shared__ uint4 tlds[TmplIO<WW, WH>::LDS_Q];   // landing area of one level's stored template
+    __shared__ uint4 tlds[SM ? 1 : TmplIO<WW, WH>::LDS_Q];   // landing area of one level's stored template
+    __shared__ float fs_[SM ? 3 * WW * WH : 1];              // "lk_sums" variants: the pixels' products, three planes
+    float* const fsum = SM ? fs_ : nullptr;
     int which = 0, b = blockIdx.x;
     if (JJ.g1 > 0) {
         // The hardware deals the workgroups of a launch to the CUs of an XCD ROUND ROBIN, by count -- not to whichever CU
@@ -397,7 +522,7 @@ __device__ __forceinline__ void lk_fast_body(const LKJobs& JJ, const LKParams& P
     const size_t t_off = (size_t)f * ((size_t)B.tmpl_levels * IO::LEVEL);   // pieces before this track's
     const TrackResult r1 = track_point_fast<WW, WH>(J.I, J.J, p0x, p0y, P, ldsI, ldsJ, lane, B.err_fwd != nullptr,
                                                     const_cast<uint4*>(static_cast<const uint4*>(B.tmpl_in)) + t_off,
-                                                    B.tmpl_in ? 1 : 0, tlds);
+                                                    !SM && B.tmpl_in ? 1 : 0, tlds, fsum);
     if (lane == 0) {
         if (B.p_fwd) { B.p_fwd[2 * f] = r1.x; B.p_fwd[2 * f + 1] = r1.y; }
         if (B.st_fwd) B.st_fwd[f] = (uint8_t)r1.status;
@@ -406,7 +531,8 @@ __device__ __forceinline__ void lk_fast_body(const LKJobs& JJ, const LKParams& P
     }
     if (FB) {
         const TrackResult r2 = track_point_fast<WW, WH>(J.J, J.I, r1.x, r1.y, P, ldsI, ldsJ, lane, B.err_bwd != nullptr,
-                                                        static_cast<uint4*>(B.tmpl_out) + t_off, B.tmpl_out ? 2 : 0, tlds);
+                                                        static_cast<uint4*>(B.tmpl_out) + t_off, !SM && B.tmpl_out ? 2 : 0, tlds,
+                                                        fsum);
         if (lane == 0) {
             if (B.p_bwd) { B.p_bwd[2 * f] = r2.x; B.p_bwd[2 * f + 1] = r2.y; }
             if (B.st_bwd) B.st_bwd[f] = (uint8_t)r2.status;
@@ -440,6 +566,13 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_num_vgpr(44))) void k_
     lk_fast_body<WW, WH, FB>(JJ, P);
 }
 
+// the same kernels under a "lk_sums" variant: the float-lane chains (chain_sums) and LDS for the pixels' products
+template <int WW, int WH, bool FB>
+__global__ __launch_bounds__(64, 2) void k_lk_fast_sums(LKJobs JJ, LKParams P)
+{
+    lk_fast_body<WW, WH, FB, true>(JJ, P);
+}
+
 int grid_of(const LKBuffers& B, int n) { return B.order ? (n + 15) & ~7 : (n + 7) & ~7; }
 
 template <int WW, int WH>
@@ -451,6 +584,11 @@ void launch_fast(hipStream_t s, const LKJob& a, const LKJob* b, const LKParams& 
     JJ.g0 = grid_of(a.B, a.n);
     JJ.g1 = b ? grid_of(b->B, b->n) : 0;
     const int grid = JJ.g0 + JJ.g1;
+    if (P.sum_mode) {
+        if (fb) hipLaunchKernelGGL((k_lk_fast_sums<WW, WH, true>), dim3(grid), dim3(64), 0, s, JJ, P);
+        else hipLaunchKernelGGL((k_lk_fast_sums<WW, WH, false>), dim3(grid), dim3(64), 0, s, JJ, P);
+        return;
+    }
     if constexpr (Cfg<WW, WH>::TPL == 1) {
         if (fb) hipLaunchKernelGGL((k_lk_fast88<WW, WH, true>), dim3(grid), dim3(64), 0, s, JJ, P);
         else hipLaunchKernelGGL((k_lk_fast88<WW, WH, false>), dim3(grid), dim3(64), 0, s, JJ, P);
@@ -502,7 +640,7 @@ bool launch_lk_fast(hipStream_t s, const Pyramid& I, const Pyramid& J, const LKB
 
 bool launch_lk_pair(hipStream_t s, const LKJob& a, const LKJob& b, const LKParams& P)
 {
-    if ((P.flags & (ICELK_FLAG_GENERIC_KERNEL | ICELK_FLAG_MULTI_PER_WAVE)) || P.sum_mode) return false;
+    if (P.flags & (ICELK_FLAG_GENERIC_KERNEL | ICELK_FLAG_MULTI_PER_WAVE)) return false;
     if (a.n <= 0 || b.n <= 0) return false;
     return dispatch_fast(s, a, &b, P, true);
 }

@@ -228,12 +228,15 @@ __device__ __forceinline__ int dot2_vvs(v2s a, uint32_t b, int c_scalar)
 
 // ---- pixel phase: template of ONE feature -------------------------------------------------------------------
 // Everything that is the same for all lanes arrives as a scalar (readlane of the owning block's registers).
+// fsum != nullptr (the "lk_sums" variants, LKParams::sum_mode): every window pixel's three products also go to LDS as
+// floats, in raster order, for the lane-ordered float sums of chain_sums (k_lk_fast.hip); tlen = pixels of each segment
+// that lie inside the window.
 template <int WW, int WH, int F, int FI>
 __device__ __forceinline__ void template_pixels(Template<WW, WH, F>& T, const uint32_t* ldsI, uint32_t W0u, uint32_t W1u, int ics,
                                                 bool i_inside, int ipx, int ipy, int liw, int lih,
                                                 const int (&trow)[Cfg<WW, WH>::TPL], const int (&tcol)[Cfg<WW, WH>::TPL],
                                                 const uint32_t (&pmask)[Cfg<WW, WH>::TPL][(Cfg<WW, WH>::S + 1) / 2], int& a11,
-                                                int& a12, int& a22)
+                                                int& a12, int& a22, float* fsum = nullptr, const int* tlen = nullptr)
 {
     using C = Cfg<WW, WH>;
     constexpr int S = C::S;
@@ -309,6 +312,18 @@ __device__ __forceinline__ void template_pixels(Template<WW, WH, F>& T, const ui
             ixs[j] = dot2(gx1, as_v2s(W1v), dot2_vvs(gx0, W0u, kRoundD)) >> W_BITS;
             iys[j] = dot2(gy1, as_v2s(W1v), dot2_vvs(gy0, W0u, kRoundD)) >> W_BITS;
         });
+        if (fsum) {
+            constexpr int NPX = WW * WH;
+            static_for<S>([&](auto jj) {
+                constexpr int j = jj;
+                if (j < tlen[k]) {
+                    const int idx = trow[k] * WW + tcol[k] + j;
+                    fsum[idx] = (float)(ixs[j] * ixs[j]);
+                    fsum[NPX + idx] = (float)(ixs[j] * iys[j]);
+                    fsum[2 * NPX + idx] = (float)(iys[j] * iys[j]);
+                }
+            });
+        }
         // gradient pairs for the dot2 form of the residual sums (pixels beyond the window's right edge and the
         // surplus lanes' pixels are masked off here, once, with the lane's constant masks), and the 2x2 matrix sums on
         // the same pairs
@@ -336,10 +351,13 @@ __device__ __forceinline__ void template_pixels(Template<WW, WH, F>& T, const ui
 // ---- pixel phase: residual of ONE feature at the window origin encoded in `jb` ------------------------------------
 // jb = byte offset of the window's first pixel inside the feature's staged search tile (wave-uniform).
 // ERR = false: b1 = sum diff*Ix, b2 = sum diff*Iy.   ERR = true: b1 = sum |diff| over the real window pixels.
+// fsum != nullptr: the two products of every window pixel also go to LDS as floats (int32 -> float, as _mm_cvtepi32_ps),
+// in raster order (trow, tcol = the segments' window rows / first columns).
 template <int WW, int WH, int F, int FI, bool ERR>
 __device__ __forceinline__ void residual_pixels(const Template<WW, WH, F>& T, const uint32_t* ldsJ, int jb, uint32_t V0u,
                                                 uint32_t V1u, const int (&joff)[Cfg<WW, WH>::TPL],
-                                                const int (&tlen)[Cfg<WW, WH>::TPL], int& b1, int& b2)
+                                                const int (&tlen)[Cfg<WW, WH>::TPL], int& b1, int& b2, float* fsum = nullptr,
+                                                const int* trow = nullptr, const int* tcol = nullptr)
 {
     using C = Cfg<WW, WH>;
     constexpr int S = C::S;
@@ -365,6 +383,20 @@ __device__ __forceinline__ void residual_pixels(const Template<WW, WH, F>& T, co
                 b1 += q < tlen[k] ? (diff[q] < 0 ? -diff[q] : diff[q]) : 0;
             });
         } else {
+            if (fsum) {
+                constexpr int NPX = WW * WH;
+                static_for<S>([&](auto qq) {
+                    constexpr int q = qq;
+                    if (q < tlen[k]) {
+                        const uint32_t gx = T.Ixp[FI][k][q / 2], gy = T.Iyp[FI][k][q / 2];
+                        const int ix = (q & 1) ? ((int)gx >> 16) : (int)(short)(gx & 0xffffu);
+                        const int iy = (q & 1) ? ((int)gy >> 16) : (int)(short)(gy & 0xffffu);
+                        const int idx = trow[k] * WW + tcol[k] + q;
+                        fsum[idx] = (float)(diff[q] * ix);
+                        fsum[NPX + idx] = (float)(diff[q] * iy);
+                    }
+                });
+            }
             static_for<(S + 1) / 2>([&](auto qq) {
                 constexpr int q = qq;
                 uint32_t dp;

@@ -468,7 +468,10 @@ def test_named_variants_equal_the_oracles(orc, synth, name, value):
             pts = orc.good_features(img0, 3000, 0.005, 5, None, 5).reshape(-1, 2)
             base = c.track_fb(0, 1, pts, (21, 21), 3, CRIT_DEFAULT)
             differs = 0
-            for win, lvl, crit in (((21, 21), 3, CRIT_DEFAULT), ((35, 35), 4, CRIT_REF), ((9, 13), 2, CRIT_DEFAULT)):
+            # the four windows of the tuned kernels (since round 4 the variants run there: k_lk_fast.hip chain_sums) and one
+            # that only the window-generic kernel takes
+            for win, lvl, crit in (((21, 21), 3, CRIT_DEFAULT), ((35, 35), 4, CRIT_REF), ((31, 31), 5, CRIT_DEFAULT),
+                                   ((15, 15), 2, CRIT_REF), ((9, 13), 2, CRIT_DEFAULT)):
                 c.set_variant(name, value)
                 got = c.track_fb(0, 1, pts, win, lvl, crit)
                 c.set_variant(name, 0)

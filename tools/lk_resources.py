@@ -19,11 +19,12 @@ for src, base in (("k_lk_fast.hip", "k_lk_fast"), ("k_lk_multi.hip", "k_lk_multi
     for line in txt.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
-            mm = re.search(base + r"(?:88)?ILi(\d+)ELi(\d+)E(?:Li(\d+)E)?Lb([01])E", m.group(1))   # k_lk_fast88: the 88-VGPR entry point
+            # k_lk_fast88: the 88-VGPR entry point; k_lk_fast_sums: the same kernel under a "lk_sums" variant
+            mm = re.search(base + r"(88|_sums)?ILi(\d+)ELi(\d+)E(?:Li(\d+)E)?Lb([01])E", m.group(1))
             cur = None
             if mm:
-                w, h, f, fb = mm.groups()
-                cur = "%s<%s,%s%s,%s>" % (base, w, h, "," + f if f else "", "true" if fb == "1" else "false")
+                kind, w, h, f, fb = mm.groups()
+                cur = "%s%s<%s,%s%s,%s>" % (base, "_sums" if kind == "_sums" else "", w, h, "," + f if f else "", "true" if fb == "1" else "false")
                 out[cur] = {}
             continue
         if cur is None:
