@@ -104,49 +104,61 @@ __global__ __launch_bounds__(1024) void k_seg_stats(const uint8_t* __restrict__ 
     }
 }
 
-// One workgroup per tile of 1024 tracks, all tiles at once: a workgroup counts the survivors in front of its tile itself
-// (n bytes of flags at most, 10 KB at C2) instead of waiting for the tiles before it -- the one-workgroup form walked
-// the tiles one after the other and took 69 us for 10 000 tracks, on the compute stream between two tracker launches.
-// Inside the tile: ballot prefix inside a wave, 16 wave totals in LDS.  The last tile writes the count.
-__global__ __launch_bounds__(1024) void k_seg_gather(const uint8_t* __restrict__ alive, int n,
-                                                     const float* __restrict__ tracks,
-                                                     const float* __restrict__ quality, int nvert, int max_vert,
-                                                     float* __restrict__ out_tracks, float* __restrict__ out_quality,
-                                                     int* __restrict__ out_count)
+// One workgroup per tile of 256 tracks, all tiles at once: a workgroup counts the survivors in front of its tile itself
+// instead of waiting for the tiles before it (the one-workgroup form of round 1 walked the tiles one after the other: 69 us
+// for 10 000 tracks, on the compute stream between two tracker launches).  Round 4: the flags in front of the tile are read
+// four at a time (they are 0 / 1 bytes: the dword's bit count is their sum) and the tiles are 256 tracks instead of 1 024 --
+// forty workgroups instead of ten for a C2 segment, each with a quarter of the dependent loads: the gather stands on the
+// compute stream between the joint launch that closes a segment and the next one (34 us of the 329 us period at C2,
+// profiles/r04_c2_timeline.txt).  Inside the tile: ballot prefix inside a wave, 4 wave totals in LDS.  The last tile writes
+// the count.
+constexpr int kGatherTile = 256;
+__global__ __launch_bounds__(kGatherTile) void k_seg_gather(const uint8_t* __restrict__ alive, int n,
+                                                            const float* __restrict__ tracks,
+                                                            const float* __restrict__ quality, int nvert, int max_vert,
+                                                            float* __restrict__ out_tracks, float* __restrict__ out_quality,
+                                                            int* __restrict__ out_count)
 {
-    __shared__ int wave_tot[16];
-    __shared__ int before;
+    constexpr int NW = kGatherTile / 64;
+    __shared__ int wave_tot[NW];
+    __shared__ int wave_before[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int base = blockIdx.x * 1024;
-    if (tid == 0) before = 0;
-    __syncthreads();
+    const int base = blockIdx.x * kGatherTile;     // a multiple of 4: the flags before it are whole dwords
     int mine = 0;
-    for (int i = tid; i < base; i += 1024) mine += alive[i] ? 1 : 0;
+    const uint32_t* a32 = reinterpret_cast<const uint32_t*>(alive);
+    for (int i = tid; i < (base >> 2); i += kGatherTile) mine += __builtin_popcount(a32[i] & 0x01010101u);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
-    if (lane == 0 && mine) atomicAdd(&before, mine);
     const int i = base + tid;
     const bool keep = i < n && alive[i];
     const unsigned long long m = __ballot(keep);
-    if (lane == 0) wave_tot[wave] = __popcll(m);
+    if (lane == 0) {
+        wave_tot[wave] = __popcll(m);
+        wave_before[wave] = mine;
+    }
     __syncthreads();
-    int wbase = 0, tile_total = 0;
+    int before = 0, wbase = 0, tile_total = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < NW; k++) {
         const int t = wave_tot[k];
+        before += wave_before[k];
         wbase += k < wave ? t : 0;
         tile_total += t;
     }
     if (keep) {
         const int j = before + wbase + __popcll(m & ((1ull << lane) - 1ull));
-        for (int v = 0; v < nvert; v++) {
-            out_tracks[((size_t)j * nvert + v) * 2] = tracks[((size_t)i * max_vert + v) * 2];
-            out_tracks[((size_t)j * nvert + v) * 2 + 1] = tracks[((size_t)i * max_vert + v) * 2 + 1];
+        const float2* src = reinterpret_cast<const float2*>(tracks) + (size_t)i * max_vert;
+        if ((reinterpret_cast<uintptr_t>(out_tracks) & 7u) == 0) {     // the caller's buffer: 8-byte stores where it allows them
+            float2* dst = reinterpret_cast<float2*>(out_tracks) + (size_t)j * nvert;
+            for (int v = 0; v < nvert; v++) dst[v] = src[v];
+        } else {
+            float* dst = out_tracks + (size_t)j * nvert * 2;
+            for (int v = 0; v < nvert; v++) { const float2 p = src[v]; dst[2 * v] = p.x; dst[2 * v + 1] = p.y; }
         }
         for (int v = 0; v + 1 < nvert; v++)
             out_quality[(size_t)j * (nvert - 1) + v] = quality[(size_t)i * (max_vert - 1) + v];
     }
-    if (out_count && tid == 0 && base + 1024 >= n) *out_count = before + tile_total;
+    if (out_count && tid == 0 && base + kGatherTile >= n) *out_count = before + tile_total;
 }
 
 // the forward-backward filter of s1:329-333 on its own: the same device function the fused tracker launches end with
@@ -206,7 +218,7 @@ void launch_seg_gather(hipStream_t s, const uint8_t* alive, int n, const float* 
         if (out_count) hipMemsetAsync(out_count, 0, sizeof(int), s);
         return;
     }
-    hipLaunchKernelGGL(k_seg_gather, dim3((n + 1023) / 1024), dim3(1024), 0, s, alive, n, tracks, quality, nvert, max_vert, out_tracks,
+    hipLaunchKernelGGL(k_seg_gather, dim3((n + kGatherTile - 1) / kGatherTile), dim3(kGatherTile), 0, s, alive, n, tracks, quality, nvert, max_vert, out_tracks,
                        out_quality, out_count);
 }
 

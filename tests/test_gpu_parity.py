@@ -561,3 +561,57 @@ def test_corners_of_forty_random_sizes(orc):
         else:
             assert got is not None and np.array_equal(np.asarray(got).reshape(-1, 2), np.asarray(ref).reshape(-1, 2)), (w, h, bs, maxc, md, mask is not None)
     c.close()
+
+
+def test_device_tail_on_the_detectors_edge_cases(orc):
+    """The detections that start a segment take the device-driven tail (k_tail.hip: rank by response bins, maxCorners cut,
+    the segment's tables from the device-side counts); icelk_good_features takes the host's (sort after the round trip).
+    On the cases where order is delicate -- a periodic frame whose corners all have the SAME response (one response bin
+    holds every key: the tie-break by raster address decides), a maxCorners cut through a run of equal responses, masks,
+    frames with no corner at all, flat patches, a pruned candidate set that falls short and is redone -- vertex 0 of the
+    new segment's tracks is the oracle's corner list, in order."""
+    from iceberg_tracking_code_amd import Context
+    rng = np.random.RandomState(5)
+    c = Context(700, 500, n_slots=1, max_pts=1 << 16)
+
+    def check(img, maxc, q, md, bs, mask=None, what=""):
+        c.upload_gray(0, img)
+        if mask is not None:
+            c.set_mask(mask)
+        ref = orc.good_features(img, maxc, q, md, mask, bs)
+        n = c.seg_detect(0, maxc, q, md, mask is not None, bs)
+        if ref is None or len(ref) == 0:
+            assert n == 0, what
+            return 0
+        tracks, _ = c.seg_read()
+        assert n == len(ref) and tracks.shape == (n, 1, 2), what
+        assert np.array_equal(tracks[:, 0, :], ref.reshape(-1, 2)), what
+        return n
+
+    yy, xx = np.mgrid[0:240, 0:320]
+    ties = (((xx // 8) + (yy // 8)) % 2 * 200 + 20).astype(np.uint8)
+    d0, h0 = c.seg_tail_stats()
+    for md in (1, 4, 10):
+        assert check(ties, 0, 0.05, md, 3, what="ties md %d" % md) > 100
+    for maxc in (1, 7, 64, 65, 500):          # the cut falls inside the run of equal responses
+        assert check(ties, maxc, 0.05, 4, 3, what="ties cut %d" % maxc) == maxc
+    assert check(np.full((200, 300), 9, np.uint8), 100, 0.01, 10, 3, what="flat") == 0
+    d1, h1 = c.seg_tail_stats()
+    assert d1 - d0 == 9 and h1 == h0          # all of them by the device-driven tail
+    for k in range(12):
+        w, h = int(rng.randint(20, 701)), int(rng.randint(20, 501))
+        img = rng.randint(0, 256, size=(h, w)).astype(np.uint8)
+        if k % 3 == 0:
+            y0, x0 = rng.randint(0, h), rng.randint(0, w)
+            img[y0:y0 + h // 3 + 1, x0:x0 + w // 3 + 1] = rng.randint(0, 256)
+        mask = (rng.randint(0, 4, size=(h, w)) > 0).astype(np.uint8) * 255 if k % 2 else None
+        check(img, 0 if k % 3 else int(rng.randint(1, 400)), 0.01, (1, 3, 10)[k % 3], (3, 5, 7, 10)[k % 4], mask, "random %d" % k)
+        c.set_mask(None)
+    # a pruned candidate set that falls short of maxCorners: the device verdict hands the tail to the host, which redoes the
+    # stage on all candidates
+    big = rng.randint(0, 256, size=(480, 640)).astype(np.uint8)
+    for maxc, md in ((400, 5), (400, 5), (400, 60), (400, 60), (150, 5)):
+        check(big, maxc, 0.005, md, 5, what="pruning history %d %d" % (maxc, md))
+    d2, h2 = c.seg_tail_stats()
+    assert h2 > h1 and d2 > d1                # both tails were taken
+    c.close()

@@ -60,15 +60,16 @@ def insts(prefix):
     return b.get("SQ_INSTS_VALU") if b else None
 out["beside_valu_insts_per_launch"] = {"corner_kernel": insts("k_eig_strip") or insts("k_eig_nms"), "k_pyramid_ahead": insts("k_pyramid<3, 64, 64>"),
                                        "min_distance_chain": sum(insts(k) or 0 for k in ("k_key_hist", "k_key_select", "k_cell_count", "k_scan",
-                                                                 "k_cell_fill", "k_suppress", "k_gather_accepted", "k_seg_order", "k_seg_init"))}
+                                                                 "k_cell_fill", "k_suppress", "k_gather_accepted", "k_seg_order", "k_seg_init",
+                                                                 "k_tail_gather", "k_tail_scatter", "k_tail_rank", "k_tail_order"))}
 mw = re.search(r"k_lk_fast(?:88)?<(\d+), (\d+), true>", lk_name)
 win = (mw.group(1), mw.group(2)) if mw else ("21", "21")
-res = json.load(open("profiles/r03_lk_resources.json"))
+res = json.load(open("profiles/r04_lk_resources.json"))
 rk = "k_lk_fast<%s,%s,true>" % win
 out.update(lk_fb_vgprs=res[rk]["vgprs"], lk_fb_waves_per_simd=res[rk]["waves_per_simd"], lk_fb_sgpr_spills=res[rk]["sgpr_spills"],
            lk_fb_scratch_bytes=res[rk].get("scratch_bytes"))
 # Mix-weighted VALU issue cost: static instruction classes of the kernel's hot straight-line blocks (tools/isa_mix.py ->
-# profiles/r03_isa_mix_*.json) x the measured issue time of each class (profiles/valu_class_cost.json).  bench.py turns
+# profiles/r04_isa_mix_lk*.json, r03_isa_mix_strip10 / pyr64 for the kernels that did not change) x the measured issue time of each class (profiles/valu_class_cost.json).  bench.py turns
 # it into the peak the achieved rate is divided by: a fraction above 1 would be an accounting error.
 cost = json.load(open("profiles/valu_class_cost.json"))["ns_per_inst_per_simd"]
 def mix_ns(path):
@@ -80,7 +81,7 @@ def mix_ns(path):
     tot = float(sum(v.values()))
     return dict(ns_per_valu_inst=sum(n * cost[k] for k, n in v.items()) / tot, hot_valu_instructions=int(tot),
                 hot_class_share={k: n / tot for k, n in v.items()}, hot_salu_per_valu=hot.get("salu", 0) / tot, source=path)
-out["valu_mix"] = {"tracker": mix_ns("profiles/r03_isa_mix_lk%s.json" % win[0]), "corner_kernel": mix_ns("profiles/r03_isa_mix_strip10.json"),
+out["valu_mix"] = {"tracker": mix_ns("profiles/r04_isa_mix_lk%s.json" % win[0]), "corner_kernel": mix_ns("profiles/r03_isa_mix_strip10.json"),
                    "pyramid_one_wave": mix_ns("profiles/r03_isa_mix_pyr64.json"),
                    "class_cost_source": "profiles/valu_class_cost.json"}
 out["counters_note"] = "counters are from the profiled run named in `source`, not from the run that prints them"
