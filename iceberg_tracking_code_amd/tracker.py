@@ -81,6 +81,9 @@ class SegmentTracker:
         self._pyr_ahead = set()   # slots whose pyramid was enqueued ahead of their step
         # how many steps ahead of a detection frame its min-distance stage / its corner candidates may start (`_step`)
         self.begin_ahead, self.prepare_ahead, self.stage_lag = 4, 6, 2
+        # frames ahead whose pyramids are enqueued (2: what the next joint launch needs; 3: one more, so that the pyramid of
+        # the frame after the next detection frame is not enqueued by the step right before the launch that needs it)
+        self.pyramids_ahead = int(os.environ.get("ICELK_PYRAMIDS_AHEAD", "2"))
         self.stage_nowait = True  # the host round trip of a detection is taken without waiting (icelk_seg_detect_stage_try)
         # the step (counted back from the detection frame) at whose end the host WAITS for a detection's counts if they have
         # not come by themselves.  0: never before the frame itself -- the tail of a detection runs on the device without the
@@ -251,7 +254,10 @@ class SegmentTracker:
         if self.lookahead:
             # pyramids of the following frames, on the copy stream, in the shadow of the tracker launch above (two ahead
             # when a joint launch may need frame c+2 at step c+1)
-            for s_k in (next_slot, next2_slot if self.pair_launch else None):
+            ahead_pyr = (next_slot, next2_slot if self.pair_launch else None)
+            if self.pair_launch and self.pyramids_ahead >= 3:
+                ahead_pyr += (slot_of.get(3),)
+            for s_k in ahead_pyr:
                 if s_k is None or s_k in self._pyr_ahead or s_k in (slot, prev) or (s_k == next_slot and self._advanced):
                     continue
                 if self._resident:
