@@ -207,23 +207,39 @@ __global__ __launch_bounds__(NT) void k_pyramid(LevelIO S, LevelIO D1, LevelIO D
         // 13.1 us, 18.8 -> 22.0 us for the one-wave geometry; the extra barrier and the extra partly filled round of tasks
         // cost more than the overlap returns.)
     } else {
-        constexpr int NDW = L0_W / 4, N = (NDW * L0_H + NT - 1) / NT;
-        uint32_t v[N];
+        // A tile at the frame edge (round 4): the same 16-byte pieces, each fetched iff its row lies inside the image and it
+        // overlaps the image's columns.  (Rounds 1-3 fetched such tiles dword by dword, 23 bounds-checked loads per thread
+        // with a division each, and -- all workgroups of a launch being resident at once -- the launch lasted as long as its
+        // slowest workgroup: 25 000 cycles for a tile on the bottom edge against 16 000 for one inside the frame,
+        // tools/pyr_stamps_run.sh.)  A piece that sticks out on the right reads up to 12 bytes of the row's padding (the
+        // pitch is a multiple of 64) or of the next row -- inside the allocation, see layout_ok -- which the edge fill
+        // overwrites or nothing looks at.  The one piece that straddles the LEFT edge (region origin -20: image columns
+        // -4 .. 11) is fetched from column 0 instead and lands 4 bytes further on, as dwords.
+        constexpr int NQ = L0_P / 16, N = (NQ * L0_H + NT - 1) / NT;
+        uint4 v[N];
         const int gx0 = x0 + L0_OX, gy0 = y0 + L0_OY;
 #pragma unroll
         for (int m = 0; m < N; m++) {
-            const int i = tid + NT * m;
-            const int r = i / NDW, c = i - r * NDW;
-            const int gy = gy0 + r, gx = gx0 + 4 * c;
-            const bool ok = i < NDW * L0_H && (unsigned)gy < (unsigned)S.h && (unsigned)gx < (unsigned)S.w;
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(S.ptr + (size_t)(ok ? gy : 0) * S.pitch + (ok ? gx : 0));
-            v[m] = ok ? *p : 0u;
+            int i = tid + NT * m;
+            i = i < NQ * L0_H ? i : NQ * L0_H - 1;
+            const int r = i / NQ, c = i - r * NQ;
+            const int gy = gy0 + r, gx = gx0 + 16 * c;
+            const bool ok = (unsigned)gy < (unsigned)S.h && gx < S.w && gx + 15 >= 0;
+            const int xl = gx < 0 ? 0 : gx;
+            v[m] = ok ? *reinterpret_cast<const uint4*>(S.ptr + (size_t)gy * S.pitch + xl) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int m = 0; m < N; m++) {
-            const int i = tid + NT * m;
-            const int r = i / NDW, c = i - r * NDW;
-            if (i < NDW * L0_H) reinterpret_cast<uint32_t*>(R0 + r * L0_P)[c] = v[m];
+            int i = tid + NT * m;
+            i = i < NQ * L0_H ? i : NQ * L0_H - 1;
+            const int r = i / NQ, c = i - r * NQ;
+            const int gx = gx0 + 16 * c;
+            if (gx < 0 && gx + 15 >= 0) {
+                uint32_t* q = reinterpret_cast<uint32_t*>(R0 + r * L0_P + (0 - gx0));   // where image column 0 sits
+                q[0] = v[m].x; q[1] = v[m].y; q[2] = v[m].z; q[3] = v[m].w;
+            } else {
+                reinterpret_cast<uint4*>(R0)[i] = v[m];
+            }
         }
     }
     // ---- stages 2-4: level 1 (region columns 2 .. W-2, every row), level 2 (columns 2 .. T0/4+4), level 3 ----
