@@ -336,9 +336,13 @@ def main():
     if cname == "c3":
         K = 64   # BASELINE.json configs[2]: 64 consecutive pairs
     linear = cname in ("c3", "c4")            # a sequence of distinct frames instead of a ping-pong ring
+    steps_note = None
     if linear and K % TRACK_LEN:
-        raise SystemExit("--steps must be a multiple of track_len (%d) for %s: a rank's block of the sequence starts and ends "
-                         "at a detection frame (sharding.frame_block)" % (TRACK_LEN, cname))
+        # a rank's block of the sequence starts and ends at a detection frame (sharding.frame_block): the timed steps are
+        # rounded down to whole segments and the line says so -- a scaling run must not die on an odd --steps
+        K_req, K = K, max(TRACK_LEN, K - K % TRACK_LEN)
+        steps_note = "--steps %d rounded to %d: %s shards by segments of track_len = %d frames" % (K_req, K, cname, TRACK_LEN)
+        sys.stderr.write("bench.py: " + steps_note + "\n")
     ring = (W + K + 1) if linear else max(2, min(args.ring, K + W + 1))
     max_pts = max(cfg["max_corners"], 1 << 14) if cfg["max_corners"] > 0 else 1 << 18
     seed = 1234
@@ -629,7 +633,7 @@ def main():
         out = {
             "metric": "frame_pairs_per_sec", "value": pairs_per_s, "unit": "frame-pairs/s",
             "tracked_features_per_sec": feats_per_s,
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / max(pairs_timed, 1),
+            "n_gpus": world, "steps": K, "steps_note": steps_note, "warmup": W, "ms_per_step": 1e3 * elapsed / max(pairs_timed, 1),
             "pairs_launched_in_timed_region": pairs_launched, "pairs_expected": K,
             "pairs_launched_by_hip_events": pairs_by_events,
             "pairs_mismatch": bool(pairs_launched != K or (pairs_by_events is not None and pairs_by_events != pairs_launched)),

@@ -615,3 +615,26 @@ def test_device_tail_on_the_detectors_edge_cases(orc):
     d2, h2 = c.seg_tail_stats()
     assert h2 > h1 and d2 > d1                # both tails were taken
     c.close()
+
+
+def test_two_pass_detector_with_candidates_prepared_under_another_quality_level(orc, synth, monkeypatch):
+    """ICELK_TWO_PASS_CORNERS=1 with icelk_seg_detect_prepare: the candidates of a coming detection are cut at the quality
+    level of the detection begun BEFORE (the level of the coming one is not known yet), and icelk_seg_detect_begin adopts
+    them only if its own level is not lower.  A lowered, then a raised, then an equal level between
+    detections: the corners are the oracle's every time."""
+    from iceberg_tracking_code_amd import Context
+    monkeypatch.setenv("ICELK_TWO_PASS_CORNERS", "1")
+    w, h = 640, 480
+    frames, _ = synth.sequence(w, h, 4, seed=12, max_step_px=2.0)
+    c = Context(w, h, n_slots=4, max_pts=1 << 15)
+    for i, f in enumerate(frames):
+        c.upload_gray(i, f)
+    prev = None
+    for slot, q in ((0, 0.05), (1, 0.005), (2, 0.05), (3, 0.05)):
+        c.seg_detect_prepare(slot, False, 10)       # cut at `prev`: higher than q for slot 1 (must not be adopted), lower for slot 2
+        n = c.seg_detect(slot, 0, q, 10, False, 10)
+        ref = orc.good_features(frames[slot], 0, q, 10, None, 10)
+        tracks, _ = c.seg_read()
+        assert n == len(ref) > 50 and np.array_equal(tracks[:, 0, :], ref.reshape(-1, 2)), (slot, q, prev)
+        prev = q
+    c.close()
