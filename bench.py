@@ -458,6 +458,7 @@ def main():
     archived = (archive["n"] - archived0) if archive else 0
     archiving = archive is not None
     pairs_by_tracker = tracker.pairs_launched - pairs0
+    tail_stats, tmpl_info = ctx.seg_tail_stats(), ctx.seg_template_info()
     consumed = tracker.abort()      # what was started ahead for frames beyond the timed steps is abandoned (it has run)
     n_live, tracked1 = tracker.live()
     elapsed = t1 - t0
@@ -653,6 +654,10 @@ def main():
                        "count_gather": gather["backend"] if gather else None},
             # which hardware queues the handle's side streams landed on: throughput depends on it, results do not
             "stream_probe": probe_info,
+            # which tail staged the segments of this handle so far (k_tail.hip / the host's: icelk_seg_tail_stats), and the
+            # template tables (icelk_seg_template_info: bytes of one of the two, rows, state)
+            "detection_tails": {"device_driven": tail_stats[0], "host": tail_stats[1]},
+            "template_tables": {"bytes_each": tmpl_info[0], "rows": tmpl_info[1], "state": tmpl_info[2]},
         }
         if gather:
             out["gather"] = gather
