@@ -540,6 +540,7 @@ def main():
         n_up_slots = depth + args.pcie_spare_slots   # previous, current, `depth` coming, and spares: the slot an upload
         # overwrites was last read several launches ago, so the copy never waits for the launch that is running
         hctx = Context(w, h, n_slots=n_up_slots, max_pts=max_pts, device=local_rank)
+        hprobe = hctx.stream_probe_info()
         # the W warm-up frames through this handle too (same loop, same source), as the resident run had them
         hw = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=hctx, lookahead=False)
         for i in range(W):
@@ -566,7 +567,7 @@ def main():
         pcie = dict(value=(len(pinned) - 1) / (h1 - h0), unit="frame-pairs/s", pairs=len(pinned) - 1,
                     tracked_features_per_sec=htracked / (h1 - h0), live_tracks_equal_resident_run=bool(ht.live()[0] == n_live),
                     source="pinned host memory, hipMemcpyAsync, %d uploads in flight ahead of the tracker (%d slots)" % (depth, n_up_slots),
-                    bytes_per_frame=w * h, note="a handle of its own, warmed up with the same W frames; includes the first frame's upload and the first "
+                    bytes_per_frame=w * h, stream_probe=hprobe, note="a handle of its own, warmed up with the same W frames; includes the first frame's upload and the first "
                          "(blocking) detection of the 65-frame batch")
         for ptr in pinned_all:
             hctx.host_free(ptr)
