@@ -57,6 +57,10 @@ struct Geo {
     static constexpr int L1_OX = -8, L1_OY = -6, L1_W = T0 / 2 + 12, L1_H = T0 / 2 + 9;   // needs [-6,T0/2+2]: columns 2.. of the region
     static constexpr int L2_OX = -4, L2_OY = -2, L2_W = T0 / 4 + 8, L2_H = T0 / 4 + 3;    // needs [-2,T0/4]: columns 2.. of the region
     static constexpr int L3_W = T0 / 8, L3_H = T0 / 8;
+    // rows per task of level 2: 35 rows x 35 columns are 245 tasks of 5 rows for 256 threads (runs of 8 left a third of
+    // the threads idle behind 19-row tasks); the one-wave geometry (19 x 19) stays one round of 57 tasks with runs of 8
+    static constexpr int L2_CH = T0 == 128 ? 5 : 8;
+    static constexpr int L1_CH = T0 == 128 ? 6 : 8;   // rows per task of level 1 (column pairs), see the call
     // LDS row pitch of the level-0 region: a multiple of 16 B, so that a tile inside the frame is fetched and stored as
     // 16-byte pieces (global_load_dwordx4 -> ds_write_b128: a quarter of the load and store instructions)
     static constexpr int L0_P = (L0_W + 15) & ~15;
@@ -118,26 +122,78 @@ __device__ __forceinline__ void pyr_level(const uint8_t* __restrict__ src, int s
     }
 }
 
-// A tile at the frame edge: the two positions next to each image edge (all a 5-tap filter centred inside the image can
-// reach) take the value of their mirror positions (BORDER_REFLECT_101), which the same region holds: first the four
-// columns -2, -1, w, w+1 over every row, then -- behind a barrier, so that the corners come out right -- the four rows
-// -2, -1, h, h+1 over every column.  (gx0, gy0) = global coordinates of region (0, 0).  A few hundred byte copies.
-template <int NT>
-__device__ __forceinline__ void fill_edges(uint8_t* __restrict__ reg, int pitch, int cols, int rows, int gx0, int gy0, int w,
-                                           int h, int tid)
+// The same for TWO adjacent output columns ox, ox + 1 whose first source byte c0 = 2*ox + scol is a multiple of 4
+// (round 4): the seven source bytes of a row are the two aligned dwords at c0, column ox sums the first dword as it
+// stands + byte 4, column ox + 1 the dword cut out at byte 2 + byte 6 -- five vector instructions per source row for
+// two columns (no lane-dependent shift) where the one-column task needs four for one.
+template <int CH>
+__device__ __forceinline__ void pyr_task_pair(const uint8_t* __restrict__ src, int spitch, int scol, uint8_t* __restrict__ dst,
+                                              int dpitch, int ox, int oy0)
 {
-    for (int i = tid; i < 4 * rows; i += NT) {
-        const int k = i & 3, r = i >> 2;
-        const int gx = k < 2 ? k - 2 : w + (k - 2);
-        const int c = gx - gx0, sc = reflect101(gx, w) - gx0;
-        if ((unsigned)c < (unsigned)cols && (unsigned)sc < (unsigned)cols) reg[r * pitch + c] = reg[r * pitch + sc];
+    constexpr int NR = 2 * CH + 3;
+    int ha[NR], hb[NR];
+    const int c0 = 2 * ox + scol;
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(src + (2 * oy0 + i) * spitch + c0);
+        const uint32_t d0 = p[0], d1 = p[1];
+        ha[i] = (int)__builtin_amdgcn_udot4(d0, 0x04060401u, d1 & 255u, false);
+        hb[i] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), 0x04060401u, (d1 >> 16) & 255u, false);
     }
-    __syncthreads();
-    for (int i = tid; i < 4 * cols; i += NT) {
-        const int k = i & 3, c = i >> 2;
-        const int gy = k < 2 ? k - 2 : h + (k - 2);
-        const int r = gy - gy0, sr = reflect101(gy, h) - gy0;
-        if ((unsigned)r < (unsigned)rows && (unsigned)sr < (unsigned)rows) reg[r * pitch + c] = reg[sr * pitch + c];
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+        const int va = ha[2 * j] + ha[2 * j + 4] + 4 * (ha[2 * j + 1] + ha[2 * j + 3]) + 6 * ha[2 * j + 2];
+        const int vb = hb[2 * j] + hb[2 * j + 4] + 4 * (hb[2 * j + 1] + hb[2 * j + 3]) + 6 * hb[2 * j + 2];
+        dst[(oy0 + j) * dpitch + ox] = (uint8_t)((va + 128) >> 8);
+        dst[(oy0 + j) * dpitch + ox + 1] = (uint8_t)((vb + 128) >> 8);
+    }
+}
+
+// One level of the tile out of column pairs: NPAIR pairs from column FIRST_COL (2*FIRST_COL + scol a multiple of 4) x ROWS
+// rows, runs of CH rows per task, the leftover rows as tasks of their own on the far threads (as in pyr_level)
+template <int NT, int CH, int NPAIR, int ROWS, int FIRST_COL>
+__device__ __forceinline__ void pyr_level_pairs(const uint8_t* __restrict__ src, int spitch, int scol, uint8_t* __restrict__ dst,
+                                                int dpitch, int tid)
+{
+    constexpr int NFULL = ROWS / CH, REM = ROWS - NFULL * CH;
+    for (int t = tid; t < NPAIR * NFULL; t += NT) {
+        const int ch = t / NPAIR;
+        pyr_task_pair<CH>(src, spitch, scol, dst, dpitch, FIRST_COL + 2 * (t - ch * NPAIR), ch * CH);
+    }
+    if constexpr (REM > 0) {
+        for (int t = NT - 1 - tid; t < NPAIR; t += NT) pyr_task_pair<REM>(src, spitch, scol, dst, dpitch, FIRST_COL + 2 * t, NFULL * CH);
+    }
+}
+
+// A tile at the frame edge: the two positions next to each image edge (all a 5-tap filter centred inside the image can
+// reach) take the value of their mirror positions (BORDER_REFLECT_101), which the same region holds.  Round 4: ONE pass
+// over the sides the region really touches (rounds 1-3: all four sides of every edge tile, columns first, a barrier, then
+// rows -- five rounds of mostly idle threads and two barriers per level, 1 500 cycles per level on every edge tile while
+// all other workgroups wait for the launch to end).  A position outside the image in x, in y or in both reads the
+// position INSIDE the image that both reflections lead to; in-image positions are never written here, so nothing read
+// in this pass is written in it, and a corner position reached from both lists gets the same value twice.
+// (gx0, gy0) = global coordinates of region (0, 0).  ROWS_TOO = false: the rows outside the image hold their mirror rows
+// already (level 0: the loads fetched them from there), only the columns are left to do.
+template <int NT, int COLS, int ROWS, bool ROWS_TOO>
+__device__ __forceinline__ void fill_edges(uint8_t* __restrict__ reg, int pitch, int gx0, int gy0, int w, int h, int tid)
+{
+    const bool left = gx0 < 0, right = gx0 + COLS > w, top = ROWS_TOO && gy0 < 0, bottom = ROWS_TOO && gy0 + ROWS > h;
+    const int n_col_items = ((left ? 2 : 0) + (right ? 2 : 0)) * ROWS, n_row_items = ((top ? 2 : 0) + (bottom ? 2 : 0)) * COLS;
+    for (int i = tid; i < n_col_items + n_row_items; i += NT) {
+        int r, c;
+        if (i < n_col_items) {
+            const int k = i / ROWS;                     // 0, 1: the first side that is there; 2, 3: the second
+            r = i - k * ROWS;
+            c = ((left && k < 2) ? k - 2 : w + (k & 1)) - gx0;
+        } else {
+            const int j = i - n_col_items, k = j / COLS;
+            c = j - k * COLS;
+            r = ((top && k < 2) ? k - 2 : h + (k & 1)) - gy0;
+        }
+        const int sc = reflect101(gx0 + c, w) - gx0, sr = ROWS_TOO ? reflect101(gy0 + r, h) - gy0 : r;
+        if ((unsigned)c < (unsigned)COLS && (unsigned)r < (unsigned)ROWS && (unsigned)sc < (unsigned)COLS &&
+            (unsigned)sr < (unsigned)ROWS)
+            reg[r * pitch + c] = reg[sr * pitch + sc];
     }
     __syncthreads();
 }
@@ -160,21 +216,46 @@ template <int NL, int T0, int NT>
 __global__ __launch_bounds__(NT) void k_pyramid(LevelIO S, LevelIO D1, LevelIO D2, LevelIO D3, unsigned long long* stamps, int tiles_x,
                                                  int tiles_y)
 {
-    // Tiles on the frame edge go first (round 4): every workgroup of the launch is resident at once and all of them ask for
-    // their level-0 regions in the same microsecond, so a workgroup's load stage is as long as its place in the memory
-    // system's queue -- and the edge tiles, which also fill their borders, were the LAST to be dispatched (the bottom row:
-    // 13 000 cycles of load stage against 7 800 inside the frame) and set the length of the launch.  Workgroup b of the 1-D
-    // grid takes: the bottom row, the top row, the left and right columns, then the interior in raster order.
+    // Which tile a workgroup takes (round 4).  Two things decide it:
+    //  * every workgroup of the launch is resident at once and all of them ask for their level-0 regions in the same
+    //    microsecond, so a workgroup's load stage is as long as its place in the memory system's queue, and the launch
+    //    lasts as long as its slowest workgroup: the tiles on the frame edge (which also fill their borders) go FIRST
+    //    (dispatched last, the bottom row had 13 000 cycles of load stage against 7 800 inside the frame);
+    //  * workgroup b runs on XCD b % 8, and every XCD has an L2 of its own: tiles that share a halo belong on ONE XCD, or
+    //    the 14-px halo (49 % of the tile's own bytes) comes out of HBM once per neighbour.  XCD k takes the k-th eighth
+    //    of the tiles in raster order -- a band of the frame -- and inside its band the left and right columns first,
+    //    then the rest row by row: downwards in the upper half of the frame, upwards in the lower half, so that the top
+    //    and the bottom row of the frame are the first rows of their bands.
     int tbx, tby;
     {
-        const int gx = tiles_x, gy = tiles_y, b = blockIdx.x;
-        const int n_edge = gy >= 2 ? 2 * gx + (gx >= 2 ? 2 : 1) * (gy - 2) : gx * gy;
-        if (gy < 3 || gx < 3) { tby = b / gx; tbx = b - tby * gx; }
-        else if (b < gx) { tbx = b; tby = gy - 1; }
-        else if (b < 2 * gx) { tbx = b - gx; tby = 0; }
-        else if (b < 2 * gx + (gy - 2)) { tbx = 0; tby = 1 + b - 2 * gx; }
-        else if (b < n_edge) { tbx = gx - 1; tby = 1 + b - 2 * gx - (gy - 2); }
-        else { const int i = b - n_edge; tby = i / (gx - 2); tbx = 1 + i - tby * (gx - 2); tby += 1; }
+        const int gx = tiles_x, n = tiles_x * tiles_y, per = (n + 7) / 8;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int a = xcd * per, e = a + per < n ? a + per : n;
+        if (a + slot >= e) return;                                   // the last bands of a grid that does not divide by 8
+        const bool up = xcd >= 4;
+        int idx;
+        if (gx < 3) {
+            idx = up ? e - 1 - slot : a + slot;
+        } else {
+            const int row_a = a / gx, row_e = e / gx;
+            const int n_left = (e + gx - 1) / gx - (a + gx - 1) / gx;   // raster indices = 0 (mod gx) in [a, e)
+            const int n_right = row_e - row_a;                          // ... = gx - 1 (mod gx)
+            if (slot < n_left) idx = ((a + gx - 1) / gx + slot) * gx;
+            else if (slot < n_left + n_right) idx = (row_a + slot - n_left) * gx + gx - 1;
+            else {
+                // the k-th tile of the band that is in neither column, counted in a raster of the gx - 2 inner columns
+                const int inner = gx - 2, k = slot - n_left - n_right;
+                auto inner_before = [&](int i) {
+                    const int c = i % gx - 1;
+                    return (i / gx) * inner + (c < 0 ? 0 : c > inner ? inner : c);
+                };
+                const int first = inner_before(a), count = inner_before(e) - first;
+                const int rank = first + (up ? count - 1 - k : k);
+                idx = (rank / inner) * gx + 1 + rank % inner;
+            }
+        }
+        tby = idx / gx;
+        tbx = idx - tby * gx;
     }
 #define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[8 * (tby * tiles_x + tbx) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     STAMP(0);
@@ -241,9 +322,10 @@ __global__ __launch_bounds__(NT) void k_pyramid(LevelIO S, LevelIO D1, LevelIO D
             i = i < NQ * L0_H ? i : NQ * L0_H - 1;
             const int r = i / NQ, c = i - r * NQ;
             const int gy = gy0 + r, gx = gx0 + 16 * c;
-            const bool ok = (unsigned)gy < (unsigned)S.h && gx < S.w && gx + 15 >= 0;
+            const bool ok = gx < S.w && gx + 15 >= 0;
             const int xl = gx < 0 ? 0 : gx;
-            v[m] = ok ? *reinterpret_cast<const uint4*>(S.ptr + (size_t)gy * S.pitch + xl) : make_uint4(0u, 0u, 0u, 0u);
+            // a row outside the image is fetched from its mirror row: the top and bottom borders of level 0 cost nothing
+            v[m] = ok ? *reinterpret_cast<const uint4*>(S.ptr + (size_t)reflect101(gy, S.h) * S.pitch + xl) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int m = 0; m < N; m++) {
@@ -262,21 +344,24 @@ __global__ __launch_bounds__(NT) void k_pyramid(LevelIO S, LevelIO D1, LevelIO D
     // ---- stages 2-4: level 1 (region columns 2 .. W-2, every row), level 2 (columns 2 .. T0/4+4), level 3 ----
     // region index (ox, oy) of a level <-> source region: column 2*ox + scol, row 2*oy, with scol = +2, -2, +2
     __syncthreads();
-    if (!interior) fill_edges<NT>(R0, L0_P, L0_W, L0_H, x0 + L0_OX, y0 + L0_OY, S.w, S.h, tid);
+    if (!interior) fill_edges<NT, L0_W, L0_H, false>(R0, L0_P, x0 + L0_OX, y0 + L0_OY, S.w, S.h, tid);
     STAMP(1);
-    pyr_level<NT, 8, L1_W - 3, L1_H, 2>(R0, L0_P, 2, R1, L1_W, tid);
+    // level 1 out of column pairs from column 1 (source byte 4): columns 1 .. L1_W - 2, of which 2 .. are needed.
+    // 128-px form: 37 pairs x (12 runs of 6 rows + 1 row) = 481 tasks, two rounds of 256 threads; one-wave form: 21 pairs x
+    // (5 runs of 8 + 1) = 126 tasks, two rounds of 64
+    pyr_level_pairs<NT, G::L1_CH, (L1_W - 2) / 2, L1_H, 1>(R0, L0_P, 2, R1, L1_W, tid);
     __syncthreads();
     STAMP(2);
     copy_out<NT>(R1, L1_W, -L1_OX, -L1_OY, T0 / 2, T0 / 8, D1, x1, y1, tid);
     STAMP(3);
     if (NL == 1) return;
-    if (!interior) fill_edges<NT>(R1, L1_W, L1_W, L1_H, x1 + L1_OX, y1 + L1_OY, D1.w, D1.h, tid);
-    pyr_level<NT, 8, L2_W - 5, L2_H, 2>(R1, L1_W, -2, R2, L2_W, tid);
+    if (!interior) fill_edges<NT, L1_W, L1_H, true>(R1, L1_W, x1 + L1_OX, y1 + L1_OY, D1.w, D1.h, tid);
+    pyr_level<NT, G::L2_CH, L2_W - 5, L2_H, 2>(R1, L1_W, -2, R2, L2_W, tid);
     __syncthreads();
     STAMP(4);
     copy_out<NT>(R2, L2_W, -L2_OX, -L2_OY, T0 / 4, T0 / 16, D2, x2, y2, tid);
     if (NL == 2) return;
-    if (!interior) fill_edges<NT>(R2, L2_W, L2_W, L2_H, x2 + L2_OX, y2 + L2_OY, D2.w, D2.h, tid);
+    if (!interior) fill_edges<NT, L2_W, L2_H, true>(R2, L2_W, x2 + L2_OX, y2 + L2_OY, D2.w, D2.h, tid);
     pyr_level<NT, 2, L3_W, L3_H, 0>(R2, L2_W, 2, R3, L3_W, tid);
     __syncthreads();
     copy_out<NT>(R3, L3_W, 0, 0, T0 / 8, T0 / 32, D3, x3, y3, tid);
@@ -300,7 +385,7 @@ static void launch_geo(hipStream_t s, const Level* lv, int first, int n)
 {
     const Level& S = lv[first];
     const int tiles_x = (S.w + T0 - 1) / T0, tiles_y = (S.h + T0 - 1) / T0;
-    dim3 grid(tiles_x * tiles_y);
+    dim3 grid(8 * ((tiles_x * tiles_y + 7) / 8));   // eight bands of equal length, see the kernel
     const LevelIO src = io_of(S), d1 = io_of(lv[first + 1]);
     const LevelIO d2 = n >= 2 ? io_of(lv[first + 2]) : d1, d3 = n >= 3 ? io_of(lv[first + 3]) : d1;
     // diagnostics: ICELK_PYR_STAMPS=<file> records s_memtime at the stage boundaries of every workgroup of each launch
