@@ -198,17 +198,27 @@ __device__ __forceinline__ void fill_edges(uint8_t* __restrict__ reg, int pitch,
     __syncthreads();
 }
 
-// the owned block of a region goes to global memory as dwords: rows [ry, ry+rows) x byte columns [rx, rx + 4*dwords)
-template <int NT>
-__device__ __forceinline__ void copy_out(const uint8_t* __restrict__ reg, int rpitch, int rx, int ry, int rows, int dwords,
-                                         const LevelIO& L, int gx0, int gy0, int tid)
+// the owned block of a region goes to global memory in pieces of PB = 16 bytes (8 for a block 8 bytes wide): rows
+// [ry, ry+ROWS) x byte columns [rx, rx + BYTES) of the region -> (gx0, gy0) of the level.  gx0 is a multiple of BYTES, the
+// level starts on a 256-B boundary and its pitch is a multiple of 64, so a piece is aligned and one that starts inside
+// the image ends inside its row's pitch (what it writes behind column w - 1 is padding nothing reads).  Round 4: one
+// 16-byte store per thread for the 64 x 64 block of level 1 where there were four dword stores with an LDS read between them.
+template <int NT, int ROWS, int BYTES>
+__device__ __forceinline__ void copy_out(const uint8_t* __restrict__ reg, int rpitch, int rx, int ry, const LevelIO& L, int gx0,
+                                         int gy0, int tid)
 {
-    for (int i = tid; i < rows * dwords; i += NT) {
-        const int r = i / dwords, c = i - r * dwords;
-        const int gy = gy0 + r, gx = gx0 + 4 * c;
-        if (gy < L.h && gx < L.w)   // a last dword may run into the row padding (pitch is a multiple of 64): harmless
-            *reinterpret_cast<uint32_t*>(L.ptr + (size_t)gy * L.pitch + gx) =
-                *reinterpret_cast<const uint32_t*>(reg + (ry + r) * rpitch + rx + 4 * c);
+    constexpr int PB = BYTES >= 16 ? 16 : 8, PPR = BYTES / PB;
+    static_assert(BYTES % PB == 0, "block width");
+    for (int i = tid; i < ROWS * PPR; i += NT) {
+        const int r = i / PPR, c = i - r * PPR;
+        const int gy = gy0 + r, gx = gx0 + PB * c;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(reg + (ry + r) * rpitch + rx + PB * c);   // 4-byte aligned
+        if (gy < L.h && gx < L.w) {
+            uint8_t* g = L.ptr + (size_t)gy * L.pitch + gx;
+            // (plain stores: with the nontemporal form the launch measured 7.8 us against 7.5)
+            if constexpr (PB == 16) *reinterpret_cast<uint4*>(g) = make_uint4(q[0], q[1], q[2], q[3]);
+            else *reinterpret_cast<uint2*>(g) = make_uint2(q[0], q[1]);
+        }
     }
 }
 
@@ -352,19 +362,19 @@ __global__ __launch_bounds__(NT) void k_pyramid(LevelIO S, LevelIO D1, LevelIO D
     pyr_level_pairs<NT, G::L1_CH, (L1_W - 2) / 2, L1_H, 1>(R0, L0_P, 2, R1, L1_W, tid);
     __syncthreads();
     STAMP(2);
-    copy_out<NT>(R1, L1_W, -L1_OX, -L1_OY, T0 / 2, T0 / 8, D1, x1, y1, tid);
+    copy_out<NT, T0 / 2, T0 / 2>(R1, L1_W, -L1_OX, -L1_OY, D1, x1, y1, tid);
     STAMP(3);
     if (NL == 1) return;
     if (!interior) fill_edges<NT, L1_W, L1_H, true>(R1, L1_W, x1 + L1_OX, y1 + L1_OY, D1.w, D1.h, tid);
     pyr_level<NT, G::L2_CH, L2_W - 5, L2_H, 2>(R1, L1_W, -2, R2, L2_W, tid);
     __syncthreads();
     STAMP(4);
-    copy_out<NT>(R2, L2_W, -L2_OX, -L2_OY, T0 / 4, T0 / 16, D2, x2, y2, tid);
+    copy_out<NT, T0 / 4, T0 / 4>(R2, L2_W, -L2_OX, -L2_OY, D2, x2, y2, tid);
     if (NL == 2) return;
     if (!interior) fill_edges<NT, L2_W, L2_H, true>(R2, L2_W, x2 + L2_OX, y2 + L2_OY, D2.w, D2.h, tid);
     pyr_level<NT, 2, L3_W, L3_H, 0>(R2, L2_W, 2, R3, L3_W, tid);
     __syncthreads();
-    copy_out<NT>(R3, L3_W, 0, 0, T0 / 8, T0 / 32, D3, x3, y3, tid);
+    copy_out<NT, T0 / 8, T0 / 8>(R3, L3_W, 0, 0, D3, x3, y3, tid);
     STAMP(5);
 }
 
