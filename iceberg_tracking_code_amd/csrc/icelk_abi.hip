@@ -1699,7 +1699,10 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
     if ((rc = dmalloc(c, &c->eo[2].max_key, 1)) || (rc = dmalloc(c, &c->eo[2].raw, (size_t)D.cand_cap)) ||
         (rc = dmalloc(c, &c->eo[2].blk_count, candidate_blocks(max_w, max_h) * 4)))
         return fail(rc);
-    for (auto& e : c->eo)
+    // the two-pass detector's scratch (three sets, ~20 MB each at 12 MP) only on a handle created with its switch set: a
+    // handle without it runs the strip kernel whatever the switch says later (launch_candidates looks at D.acand)
+    if (getenv("ICELK_TWO_PASS_CORNERS"))
+      for (auto& e : c->eo)
         if ((rc = dmalloc(c, &e.acand, fast_cand_entries(max_w, max_h))) || (rc = dmalloc(c, &e.acount, fast_tiles(max_w, max_h))) ||
             (rc = dmalloc(c, &e.amaxc, fast_max_entries(max_w, max_h))) || (rc = dmalloc(c, &e.amaxn, fast_tiles(max_w, max_h))) ||
             (rc = dmalloc(c, &e.aemax, fast_tiles(max_w, max_h))) || (rc = dmalloc(c, &e.fmax_key, 8)) ||
@@ -2322,6 +2325,7 @@ int icelk_detect_fast_stats(icelk_t* h, int slot_w, int slot_h, long long* out)
     HIPCHK(c, hipDeviceSynchronize());
     det_save(c);
     const Ctx::EigOut& e = c->eo[c->eo_active];
+    if (!e.acand) FAIL(c, ICELK_EARG, "the two-pass detector was not enabled when this handle was created (ICELK_TWO_PASS_CORNERS)");
     const size_t nt = fast_tiles(slot_w, slot_h);
     std::vector<int> cnt(nt), mx(nt);
     unsigned fk[3] = {0, 0, 0};

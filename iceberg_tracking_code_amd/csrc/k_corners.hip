@@ -1266,7 +1266,7 @@ void launch_candidates(hipStream_t s, DetectScratch& D, const Level& img, int bl
     CandSrc g_src{};
     // ICELK_TWO_PASS_CORNERS=1: the two-pass form (k_corners_fast.hip: integer bracket of the map + exact arithmetic at the
     // possible maxima) -- a third statement of the arithmetic, bit-identical, measured and not the default
-    const bool two_pass = getenv("ICELK_TWO_PASS_CORNERS") != nullptr;
+    const bool two_pass = D.acand != nullptr && getenv("ICELK_TWO_PASS_CORNERS") != nullptr;   // scratch: at icelk_create, under the same switch
     if (two_pass && !use_generic && fused_block_size(block_size) && !eig_out_or_null &&
         launch_candidates_fast(s, D, img, block_size, mask, mask_pitch, quality))
         return;

@@ -527,6 +527,29 @@ def test_pyramid_of_forty_random_sizes(orc):
     c.close()
 
 
+@pytest.mark.parametrize("w,h", [(1401, 1150), (2100, 390), (400, 1900)])
+def test_pyramid_tile_bands_that_do_not_divide_by_eight(orc, w, h):
+    """Round 4: workgroup b of the pyramid launch takes a tile of the band of XCD b % 8 -- the left and right columns of the band
+    first, then its inner tiles downwards (upper half of the frame) or upwards (lower half).  Frames whose tile count is no
+    multiple of eight (11 x 9 = 99 and 22 x 18 = 396 tiles; 17 x 4; 4 x 15: a short last band, workgroups with no tile),
+    bands that begin and end in the middle of a tile row, both geometries, every level against the oracle."""
+    from iceberg_tracking_code_amd import Context
+    rng = np.random.RandomState(w + h)
+    img = rng.randint(0, 256, size=(h, w)).astype(np.uint8)
+    ref = orc.build_pyramid(img, (3, 3), 5)
+    c = Context(w, h, n_slots=1, max_pts=64)
+    try:
+        for ahead in (False, True):
+            c.upload_gray(0, img)
+            if ahead:
+                c.build_pyramid_ahead(0, (3, 3), 5)
+            assert c.build_pyramid(0, (3, 3), 5) == len(ref) - 1
+            for l, r in enumerate(ref):
+                assert np.array_equal(c.download_level(0, l), r), (ahead, l)
+    finally:
+        c.close()
+
+
 def test_corners_of_forty_random_sizes(orc):
     """The strip kernel walks strips of 245 x 58 outputs (blockSize 10) with per-thread reflected column offsets, reflected
     row loads for the strips at the top and bottom, a register ring that the row loop must meet in phase, and regions of 16
