@@ -229,6 +229,33 @@ def cpu_baseline(cfg, motion):
     return out
 
 
+def numa_placement(device_index):
+    """NUMA node of the device (sysfs, by PCI bus id) and of the CPU this process runs on -- pinned buffers are placed by
+    the allocating thread's policy; a remote node costs the copy engine bandwidth.  None where sysfs does not say."""
+    out = {"cpu": None, "cpu_node": None, "gpu_node": None}
+    try:
+        out["cpu"] = cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else None
+        import glob
+        for nd in glob.glob("/sys/devices/system/node/node[0-9]*"):
+            cpus = set()
+            for part in open(nd + "/cpulist").read().strip().split(","):
+                if part:
+                    a, _, b = part.partition("-")
+                    cpus.update(range(int(a), int(b or a) + 1))
+            if cpu in cpus:
+                out["cpu_node"] = int(nd.rsplit("node", 1)[1])
+        import torch
+        bus = torch.cuda.get_device_properties(device_index).pci_bus_id if hasattr(torch.cuda.get_device_properties(device_index), "pci_bus_id") else None
+        dom = getattr(torch.cuda.get_device_properties(device_index), "pci_domain_id", 0)
+        dev = getattr(torch.cuda.get_device_properties(device_index), "pci_device_id", 0)
+        if bus is not None:
+            path = "/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node" % (dom, bus, dev)
+            out["gpu_node"] = int(open(path).read().strip())
+    except Exception as e:       # diagnostics only
+        out["error"] = repr(e)
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU), BEFORE anything in
     this process has touched the GPU -- no exec of a process that has initialised HIP, the children are plain child
@@ -551,23 +578,39 @@ def main():
         hctx.sync()
         torch.cuda.synchronize()
         _, htracked0 = hctx.seg_live() if hw.active else (0, 0)
+        # what the link gives THIS process for THESE buffers, with nothing else on the device: 16 uploads into slots nothing
+        # reads (the loop below starts by overwriting them); and where the buffers and the device sit (NUMA nodes)
+        spare = [s_ for s_ in range(n_up_slots) if s_ not in (hw.cur, (hw.cur - 1) % n_up_slots)]
+        u0 = time.perf_counter()
+        for i in range(16):
+            hctx.upload_gray_async(spare[i % len(spare)], pinned[i % len(pinned)], w, h, w)
+        hctx.sync()
+        raw_upload_us = 1e6 * (time.perf_counter() - u0) / 16
+        numa = numa_placement(local_rank)
         h0 = time.perf_counter()
         for i in range(min(depth, len(pinned))):
             ht.prefetch_pinned(pinned[i], w)
+        step_t = [h0]
         for i in range(len(pinned)):
             if i + depth < len(pinned):
                 ht.prefetch_pinned(pinned[i + depth], w)
             ht.push_prefetched(wait=False)
+            step_t.append(time.perf_counter())
         hctx.sync()
         torch.cuda.synchronize()
         h1 = time.perf_counter()
+        step_us = np.diff(np.array(step_t + [h1])) * 1e6     # the host's time per frame; the last entry is the final wait
         _, htracked = ht.live()
         htracked -= htracked0
         # same frames, same loop: the survivors must agree with the resident run
         pcie = dict(value=(len(pinned) - 1) / (h1 - h0), unit="frame-pairs/s", pairs=len(pinned) - 1,
                     tracked_features_per_sec=htracked / (h1 - h0), live_tracks_equal_resident_run=bool(ht.live()[0] == n_live),
                     source="pinned host memory, hipMemcpyAsync, %d uploads in flight ahead of the tracker (%d slots)" % (depth, n_up_slots),
-                    bytes_per_frame=w * h, stream_probe=hprobe, note="a handle of its own, warmed up with the same W frames; includes the first frame's upload and the first "
+                    bytes_per_frame=w * h, stream_probe=hprobe, raw_upload_us=raw_upload_us,
+                    raw_upload_GBps=w * h / raw_upload_us / 1e3, numa=numa,
+                    host_us_per_frame=dict(median=float(np.median(step_us[:-1])), longest=float(step_us[:-1].max()),
+                                           longest_at=int(step_us[:-1].argmax()), first8=[round(float(x), 1) for x in step_us[:8]],
+                                           final_wait=float(step_us[-1])), note="a handle of its own, warmed up with the same W frames; includes the first frame's upload and the first "
                          "(blocking) detection of the 65-frame batch")
         for ptr in pinned_all:
             hctx.host_free(ptr)

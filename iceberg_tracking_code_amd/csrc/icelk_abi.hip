@@ -1761,6 +1761,19 @@ int icelk_create(int device, int max_w, int max_h, int n_slots, int max_pts, ice
         c->err = "hipMemset failed";
         return fail(ICELK_EHIP);
     }
+    // The host's tail (detect_finish) sorts with rocPRIM, and the first launch of its kernels in a process costs the host
+    // ~8 ms (the code object of k_sort.hip is loaded then).  With the device-driven tail that first time was some
+    // detection in the MIDDLE of a run -- the first one the device handed back -- and a 64-pair batch lasted 26 ms instead
+    // of 17 (profiles/r04_c3_stall.txt).  Paid here instead: 64 keys through the sort, once per handle.
+    if (hipMemsetAsync(c->D.acc, 0, 64 * sizeof(unsigned long long), c->tail_stream) != hipSuccess) {
+        c->err = "hipMemset failed";
+        return fail(ICELK_EHIP);
+    }
+    sort_keys_desc(c->tail_stream, c->D, c->D.acc, c->D.acc_sorted, 64);
+    if (hipStreamSynchronize(c->tail_stream) != hipSuccess) {
+        c->err = "warm-up sort failed";
+        return fail(ICELK_EHIP);
+    }
     *out = reinterpret_cast<icelk_t*>(c);
     return ICELK_OK;
 }

@@ -1324,14 +1324,19 @@ void launch_flatten(hipStream_t s, DetectScratch& D, double quality)
 // D.acc (unsorted accepted keys), D.acc_count; the number of thresholded candidates ends in
 // D.cell_start[ncell].  D.undecided[kSuppressLaunches-1] != 0 afterwards means "not converged, call
 // continue_min_distance".
-constexpr int kSuppressLaunches = 2;
+// Three launches since round 4 (two before): one detection in a hundred left one or two candidates undecided after the
+// second (their blockers were decided in the same launch, after the last poll) and went through the host's tail
+// (detect_finish: more launches, a host round trip each, rocPRIM's sort) instead of the device's -- 300 us, and 8 ms the
+// first time in a process (profiles/r04_c3_stall.txt).  A third launch picks up what the second left and returns at once
+// when that is nothing; the follow-up launches use a small grid (a handful of candidates, every workgroup scans the list).
+constexpr int kSuppressLaunches = 3;
 static void suppress_launches(hipStream_t s, DetectScratch& D, int w, int h, double min_distance)
 {
     const int cell = (int)lrint(min_distance);
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     const double md2 = min_distance * min_distance;
     for (int r = 0; r < kSuppressLaunches; r++)
-        hipLaunchKernelGGL(k_suppress, dim3(4096), dim3(CT), 0, s, D.cell_cand, D.cell_start + gw * gh, cell, gw, gh,
+        hipLaunchKernelGGL(k_suppress, dim3(r < 2 ? 4096 : 512), dim3(CT), 0, s, D.cell_cand, D.cell_start + gw * gh, cell, gw, gh,
                            D.cell_start, D.state, md2, D.undecided, r);
 }
 
