@@ -45,6 +45,9 @@ struct Ctx {
     // (completion signal of the first, dependency of the second: 220 us copies came out 270 us apart), which a copy
     // queued on the other stream fills
     hipStream_t copy_stream2 = nullptr;
+    // the streams of icelk_upload_gray_async since round 4: created at the first such upload, HIGH priority -- a stream of
+    // the compute stream's class can share its hardware queue, and then the copy's dependencies wait behind a tracker launch
+    hipStream_t copy_hi[2] = {nullptr, nullptr};
     hipStream_t copy_more[2] = {nullptr, nullptr};   // ICELK_COPY_STREAMS=3|4 (A/B measurements)
     int n_copy_streams = 2;
     unsigned upload_seq = 0;
@@ -748,6 +751,11 @@ static void destroy_ctx(Ctx* c)
             if (p) hipFree(p);
     }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
+    for (auto q : c->copy_hi)
+        if (q) {
+            hipStreamSynchronize(q);
+            hipStreamDestroy(q);
+        }
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->copy_stream2) {
         hipStreamSynchronize(c->copy_stream2);
@@ -1806,6 +1814,8 @@ int icelk_sync(icelk_t* h)
     // (icelk_seg_detect_prepare), the min-distance / sort / emit stage, tracker launches
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream2));
+    for (auto q : c->copy_hi)
+        if (q) HIPCHK(c, hipStreamSynchronize(q));
     for (auto q : c->copy_more)
         if (q) HIPCHK(c, hipStreamSynchronize(q));
     HIPCHK(c, hipStreamSynchronize(c->pyr_stream));
@@ -1875,8 +1885,16 @@ int icelk_upload_gray_async(icelk_t* h, int slot, const uint8_t* pinned_host, in
     int rc = begin_frame(c, slot, w, h_);
     if (rc) return rc;
     Slot& s = c->slots[slot];
+    // Two streams in turn (see Ctx::copy_stream), of the high-priority class.  With streams of the compute stream's own class
+    // every second upload -- always those of ONE of the two streams -- started 60-180 us after the copy before it had
+    // ended (profiles/r04_c3_modes.txt): that stream shared its hardware queue with the compute stream, and the barrier
+    // that carries an upload's dependencies stood behind a 250-us tracker launch.  C3 with 6 uploads in flight:
+    // 3 650-3 800 -> 4 040-4 110 pairs/s (profiles/r04_c3_copy_prio.txt).  ICELK_COPY_PRIORITY=normal: the streams of before.
+    static const bool copy_normal = getenv("ICELK_COPY_PRIORITY") && !strcmp(getenv("ICELK_COPY_PRIORITY"), "normal");
     const unsigned useq = c->upload_seq++ % (unsigned)c->n_copy_streams;
-    const hipStream_t cs = useq == 0 ? c->copy_stream : (useq == 1 ? c->copy_stream2 : c->copy_more[useq - 2]);
+    if (!copy_normal && useq < 2 && !c->copy_hi[useq])
+        HIPCHK(c, create_priority_stream(&c->copy_hi[useq]));
+    const hipStream_t cs = useq >= 2 ? c->copy_more[useq - 2] : (!copy_normal ? c->copy_hi[useq] : (useq == 0 ? c->copy_stream : c->copy_stream2));
     // the copy must not overtake the launches that still read this slot (Slot::used / det_used)
     if (int rcw = wait_event(c, cs, s.used)) return rcw;
     if (s.pending) if (int rcw = wait_event(c, cs, s.ready)) return rcw;   // an upload or a pyramid built ahead still in flight
