@@ -313,6 +313,10 @@ def main():
     ap.add_argument("--lk-sums", type=int, default=0, choices=(0, 1, 2),
                     help="icelk_set_variant('lk_sums'): 0 = exact sums (default), 1 / 2 = the float-lane order of OpenCV 3.x's SSE2 / "
                          "4.x's CV_SIMD128 block (DESIGN.md section 2); the rate under a variant is reported, never the headline")
+    ap.add_argument("--settle-ms", type=float, default=150.0,
+                    help="keep the device busy with the same loop for this long BEFORE the W warm-up steps (untimed): the device's "
+                         "clocks take tens of milliseconds of load to settle, and a 20-step window is 3.5 ms long "
+                         "(profiles/r04_short_run_sweep.txt).  0: none")
     ap.add_argument("--no-archive", action="store_true",
                     help="A/B: finished segments are not compacted into the device archive inside the timed region "
                          "(the loop's output, s1:394-395, is then left out of it)")
@@ -412,8 +416,11 @@ def main():
     # ring configs: the visiting order runs on beyond the timed steps, so that the last timed steps look ahead (corner
     # candidates, min-distance stages, pyramids and joint launches for the frames that follow) exactly as the warm-up looked
     # ahead for the first timed steps -- the timed region is a window of the steady state: K pairs go out inside it
-    order = list(range(ring)) if linear else ping_pong(ring, K + W + SegmentTracker.MAX_AHEAD)
+    settle_max = int(args.settle_ms * 1e3 / 100.0) + 64 if args.settle_ms > 0 else 0   # steps, were a step to last only 100 us
+    order = list(range(ring)) if linear else ping_pong(ring, settle_max + K + W + SegmentTracker.MAX_AHEAD)
     archive = None
+    settle = dict(ms_asked=args.settle_ms, ms=0.0, steps=0,
+                  note="untimed: the same loop before the W warm-up steps, so that the timed window sees settled clocks")
 
     def ring_archive(tracker):
         """The loop's output (s1:394-395: one `tracks` / `trackquality` pair per finished segment): every finished segment is
@@ -435,6 +442,14 @@ def main():
     if linear:
         # warm-up on the W frames before the rank's block with a tracker of its own that starts nothing ahead of time:
         # the timed tracker begins with a clean handle (no detection in flight, no staged segment)
+        ts0 = time.perf_counter()
+        while args.settle_ms > 0 and W > 0 and (time.perf_counter() - ts0) * 1e3 < args.settle_ms:
+            pre = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx, lookahead=False)
+            run_resident(pre, order[:W], 0, W)
+            ctx.sync()
+            pre.abort()
+            settle["steps"] += W
+        settle["ms"] = (time.perf_counter() - ts0) * 1e3
         warm = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx, lookahead=False)
         run_resident(warm, order[:W], 0, W)
         tracker = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx, lookahead=not args.no_lookahead, pair_launch=not args.no_pair_launch)
@@ -461,9 +476,15 @@ def main():
         tracker = SegmentTracker(w, h, TRACK_LEN, feature_params=fp, lk_params=lk, ctx=ctx, lookahead=not args.no_lookahead, pair_launch=not args.no_pair_launch)
         if not args.no_archive:
             archive = ring_archive(tracker)
-        run_resident(tracker, order, 0, W)
+        ts0, S = time.perf_counter(), 0
+        while args.settle_ms > 0 and S + 32 <= settle_max and (time.perf_counter() - ts0) * 1e3 < args.settle_ms:
+            run_resident(tracker, order, S, 32)
+            ctx.sync()
+            S += 32
+        settle["steps"], settle["ms"] = S, (time.perf_counter() - ts0) * 1e3
+        run_resident(tracker, order, S, W)
         timed_order = order
-        t_first, pushes = W, K        # steady state: every push tracks one pair
+        t_first, pushes = S + W, K    # steady state: every push tracks one pair
     barrier()
     _, tracked0 = tracker.live() if tracker.active else (0, 0)
     if linear:
@@ -500,7 +521,7 @@ def main():
     pairs_timed = pairs_launched
     # segments that closed inside the timed region: detection frames among the timed steps (the first frame of a fresh
     # tracker only starts a segment)
-    first_counter = 0 if linear else W
+    first_counter = 0 if linear else t_first
     segments_expected = len([c for c in range(first_counter, first_counter + pushes) if c % TRACK_LEN == 0 and c > 0])
 
     # ---- the same kernels once more, each ALONE on the device (outside the timed region): inside the pipeline their
@@ -678,7 +699,7 @@ def main():
         out = {
             "metric": "frame_pairs_per_sec", "value": pairs_per_s, "unit": "frame-pairs/s",
             "tracked_features_per_sec": feats_per_s,
-            "n_gpus": world, "steps": K, "steps_note": steps_note, "warmup": W, "ms_per_step": 1e3 * elapsed / max(pairs_timed, 1),
+            "n_gpus": world, "steps": K, "steps_note": steps_note, "warmup": W, "settle": settle, "ms_per_step": 1e3 * elapsed / max(pairs_timed, 1),
             "pairs_launched_in_timed_region": pairs_launched, "pairs_expected": K,
             "pairs_launched_by_hip_events": pairs_by_events,
             "pairs_mismatch": bool(pairs_launched != K or (pairs_by_events is not None and pairs_by_events != pairs_launched)),
