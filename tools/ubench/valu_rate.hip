@@ -24,7 +24,7 @@ enum Op {
     OP_ADD_U32, OP_XAD_U32, OP_MUL_I24, OP_MAD_I24, OP_DOT2_I16, OP_PERM, OP_ALIGNBYTE, OP_PK_ADD_U16, OP_PK_MAD_U16,
     OP_PK_MUL_LO_U16, OP_MUL_LO_U32, OP_FMA_F32, OP_PK_FMA_F32, OP_ADD_DPP, OP_CNDMASK, OP_LSHRREV, OP_READLANE,
     OP_S_ADD, OP_DS_READ_B32, OP_ASHRREV, OP_CNDMASK_E64, OP_DOT2C, OP_MOV, OP_ADD3, OP_LSHL_OR, OP_RNDNE, OP_CVT_I32_F32,
-    OP_CVT_F64_I32, OP_ADD_F64, OP_MUL_F64, OP_CVT_F32_F64, OP_DS_READ_B64, OP_DS_READ2_B32, OP_AND_OR, OP_MAX_I32, OP_COUNT
+    OP_CVT_F64_I32, OP_ADD_F64, OP_MUL_F64, OP_CVT_F32_F64, OP_DS_READ_B64, OP_DS_READ2_B32, OP_AND_OR, OP_MAX_I32, OP_CMP_CND_VCC, OP_CMP_CND_SGPR, OP_CMP_VCC, OP_CMP_SGPR, OP_ALIGNBIT, OP_BFE, OP_MIN_U32, OP_SUB_U32, OP_AND, OP_OR, OP_LSHL_ADD, OP_MED3, OP_COUNT
 };
 static const char* kNames[OP_COUNT] = {
     "v_add_u32", "v_xad_u32", "v_mul_i32_i24", "v_mad_i32_i24", "v_dot2_i32_i16", "v_perm_b32", "v_alignbyte_b32",
@@ -33,6 +33,9 @@ static const char* kNames[OP_COUNT] = {
     "ds_read_b32 (+ lgkmcnt wait per 16)", "v_ashrrev_i32", "v_cndmask_b32_e64 (SGPR-pair mask)", "v_dot2c_i32_i16 (VOP2)",
     "v_mov_b32", "v_add3_u32", "v_lshl_or_b32", "v_rndne_f32", "v_cvt_i32_f32", "v_cvt_f64_i32", "v_add_f64", "v_mul_f64",
     "v_cvt_f32_f64", "ds_read_b64 (+ wait per 16)", "ds_read2_b32 (+ wait per 16)", "v_and_or_b32", "v_max_i32",
+    "v_cmp_gt_i32 vcc + v_cndmask vcc (per instruction)", "v_cmp_gt_i32 s[..] + v_cndmask s[..] (per instruction)",
+    "v_cmp_gt_i32_e32 (-> vcc)", "v_cmp_gt_i32_e64 (-> SGPR pair)", "v_alignbit_b32", "v_bfe_u32", "v_min_u32", "v_sub_u32",
+    "v_and_b32", "v_or_b32", "v_lshl_add_u32", "v_med3_i32",
 };
 
 template <int OP>
@@ -83,6 +86,42 @@ __global__ __launch_bounds__(256) void k(unsigned* out, unsigned long long* tick
         else if constexpr (OP == OP_LSHL_OR) BODY4("v_lshl_or_b32");
         else if constexpr (OP == OP_AND_OR) BODY4("v_and_or_b32");
         else if constexpr (OP == OP_MAX_I32) BODY3("v_max_i32");
+        else if constexpr (OP == OP_ALIGNBIT) BODY4("v_alignbit_b32");
+        else if constexpr (OP == OP_BFE) BODY4("v_bfe_u32");
+        else if constexpr (OP == OP_MIN_U32) BODY3("v_min_u32");
+        else if constexpr (OP == OP_SUB_U32) BODY3("v_sub_u32");
+        else if constexpr (OP == OP_AND) BODY3("v_and_b32");
+        else if constexpr (OP == OP_OR) BODY3("v_or_b32");
+        else if constexpr (OP == OP_LSHL_ADD) BODY4("v_lshl_add_u32");
+        else if constexpr (OP == OP_MED3) BODY4("v_med3_i32");
+        else if constexpr (OP == OP_CMP_CND_VCC) {
+#define P(i) "v_cmp_gt_i32 vcc, %" #i ", %8\nv_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+            asm volatile(REP8(P)
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)
+                         : "v"(c) : "vcc");
+#undef P
+        } else if constexpr (OP == OP_CMP_CND_SGPR) {
+            unsigned long long m;
+#define P(i) "v_cmp_gt_i32 %9, %" #i ", %8\nv_cndmask_b32 %" #i ", %" #i ", %8, %9\n"
+            asm volatile(REP8(P)
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)
+                         : "v"(c), "s"(m = 0));
+#undef P
+        } else if constexpr (OP == OP_CMP_VCC) {
+#define P(i) "v_cmp_gt_i32 vcc, %" #i ", %8\n"
+            asm volatile(REP8(P) REP8(P) : : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5), "v"(r6), "v"(r7), "v"(c) : "vcc");
+#undef P
+        } else if constexpr (OP == OP_CMP_SGPR) {
+            unsigned long long m;
+#define P(i) "v_cmp_gt_i32 %0, %" "1" ", %9\n"
+            asm volatile("v_cmp_gt_i32 %0, %1, %9\nv_cmp_gt_i32 %0, %2, %9\nv_cmp_gt_i32 %0, %3, %9\nv_cmp_gt_i32 %0, %4, %9\n"
+                         "v_cmp_gt_i32 %0, %5, %9\nv_cmp_gt_i32 %0, %6, %9\nv_cmp_gt_i32 %0, %7, %9\nv_cmp_gt_i32 %0, %8, %9\n"
+                         "v_cmp_gt_i32 %0, %1, %9\nv_cmp_gt_i32 %0, %2, %9\nv_cmp_gt_i32 %0, %3, %9\nv_cmp_gt_i32 %0, %4, %9\n"
+                         "v_cmp_gt_i32 %0, %5, %9\nv_cmp_gt_i32 %0, %6, %9\nv_cmp_gt_i32 %0, %7, %9\nv_cmp_gt_i32 %0, %8, %9\n"
+                         : "=s"(m) : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5), "v"(r6), "v"(r7), "v"(c));
+#undef P
+            r0 ^= (unsigned)m & 1u;
+        }
         else if constexpr (OP == OP_MOV) {
 #define D(i) "v_mov_b32 %" #i ", %8\n"
             asm volatile(REP8(D) REP8(D)
@@ -287,6 +326,18 @@ int main()
     run<OP_LSHL_OR>(d_out, d_ticks, n_cu, clock_hz);
     run<OP_AND_OR>(d_out, d_ticks, n_cu, clock_hz);
     run<OP_MAX_I32>(d_out, d_ticks, n_cu, clock_hz);
+    run<OP_CMP_CND_VCC>(d_out, d_ticks, n_cu, clock_hz);
+    run<OP_CMP_CND_SGPR>(d_out, d_ticks, n_cu, clock_hz);
+    run<OP_CMP_VCC>(d_out, d_ticks, n_cu, clock_hz);
+    run<OP_CMP_SGPR>(d_out, d_ticks, n_cu, clock_hz);
+    run<OP_ALIGNBIT>(d_out, d_ticks, n_cu, clock_hz);
+    run<OP_BFE>(d_out, d_ticks, n_cu, clock_hz);
+    run<OP_MIN_U32>(d_out, d_ticks, n_cu, clock_hz);
+    run<OP_SUB_U32>(d_out, d_ticks, n_cu, clock_hz);
+    run<OP_AND>(d_out, d_ticks, n_cu, clock_hz);
+    run<OP_OR>(d_out, d_ticks, n_cu, clock_hz);
+    run<OP_LSHL_ADD>(d_out, d_ticks, n_cu, clock_hz);
+    run<OP_MED3>(d_out, d_ticks, n_cu, clock_hz);
     run<OP_RNDNE>(d_out, d_ticks, n_cu, clock_hz);
     run<OP_CVT_I32_F32>(d_out, d_ticks, n_cu, clock_hz);
     run<OP_CVT_F64_I32>(d_out, d_ticks, n_cu, clock_hz);
