@@ -767,7 +767,19 @@ def main():
             if alone.get("pyrdown"):
                 a_us = alone["pyrdown"]["total_ms"] * 1e3 / 5.0
                 kern["pyramid"].update(alone_us_per_frame=a_us, alone_GBps=alg / (a_us * 1e-6) / 1e9,
-                                       alone_frac=alg / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+                                       alone_frac=alg / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                       alone_note="HIP events around each launch: 2-2.5 us more than the kernel itself lasts")
+            # the kernel's own duration (rocprofv3 --kernel-trace --stats of tools/pyr_alone.py at 4000x3000, committed)
+            stats = os.path.join(ROOT, "profiles", "r04_pyramid_alone_kernel_stats.csv")
+            if cname in ("c2", "c3", "c4") and os.path.exists(stats):
+                try:
+                    import csv
+                    row = [r for r in csv.DictReader(open(stats)) if "k_pyramid" in r["Name"]][0]
+                    k_us = float(row["AverageNs"]) / 1e3
+                    kern["pyramid"].update(rocprof_kernel_us=k_us, rocprof_frac=alg / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                           rocprof_source="profiles/r04_pyramid_alone_kernel_stats.csv (a committed profile, not this run)")
+                except Exception:
+                    pass
         if alone.get("bgr2gray"):
             alg = 4.0 * w * h
             a_us = alone["bgr2gray"]["avg_us"]
