@@ -784,7 +784,18 @@ def main():
             alg = 4.0 * w * h
             a_us = alone["bgr2gray"]["avg_us"]
             kern["bgr2gray"] = {"bound": "hbm", "algorithmic_bytes_per_frame": alg, "alone_us": a_us,
-                                "alone_GBps": alg / (a_us * 1e-6) / 1e9, "alone_frac": alg / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                                "alone_GBps": alg / (a_us * 1e-6) / 1e9, "alone_frac": alg / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                "alone_note": "HIP events around each launch: 2-3.5 us more than the kernel itself lasts"}
+            stats = os.path.join(ROOT, "profiles", "r04_gray_alone_kernel_stats.csv")
+            if cname in ("c2", "c3", "c4") and os.path.exists(stats):
+                try:
+                    import csv
+                    row = [r for r in csv.DictReader(open(stats)) if "k_bgr2gray" in r["Name"]][0]
+                    k_us = float(row["AverageNs"]) / 1e3
+                    kern["bgr2gray"].update(rocprof_kernel_us=k_us, rocprof_frac=alg / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                            rocprof_source="profiles/r04_gray_alone_kernel_stats.csv (tools/gray_alone.py; a committed profile, not this run)")
+                except Exception:
+                    pass
         eg = prof.get("corner_candidates")
         if eg or alone.get("corner_candidates"):
             alg = 1.0 * w * h   # 1 B/px in; the eigenvalue map is never materialised (k_corners.hip)
