@@ -163,6 +163,48 @@ def test_track_fb_bit_exact(ctx, orc, synth, win, maxlevel, crit):
     assert np.median(e) < 0.05 and np.percentile(e, 95) < 0.15
 
 
+def test_pyrlk_of_thirty_random_configurations(orc, synth):
+    """The tracker kernels are chosen by window (15 / 21 / 31 / 35 square: the tuned one-feature-per-wave kernels; anything else:
+    the generic one), and inside them tiles, segment tables and level loops depend on window, level count and frame size.
+    Thirty random draws of all of that -- frames from 24 x 24 to 700 x 500 (smaller than a window, odd, not a multiple of
+    anything), windows 3 .. 45 in each direction (even, odd, not square) with the tuned sizes over-represented, maxLevel 0 .. 5,
+    every criteria type with counts 1 .. 40 and epsilons from 0 to 0.1, initial guesses, the minEig error flag, points inside,
+    on and beyond the borders -- through icelk_pyrlk and through the fused forward + backward launch, every output bit for
+    bit against the oracle."""
+    from iceberg_tracking_code_amd import Context
+    rng = np.random.RandomState(20261005)
+    c = Context(704, 512, n_slots=2, max_pts=4096)
+    tuned = [(15, 15), (21, 21), (31, 31), (35, 35)]
+    try:
+        for case in range(30):
+            w, h = int(rng.randint(24, 701)), int(rng.randint(24, 501))
+            win = tuned[rng.randint(4)] if rng.rand() < 0.4 else (int(rng.randint(3, 46)), int(rng.randint(3, 46)))
+            maxlevel = int(rng.randint(0, 6))
+            ctype = int(rng.randint(1, 4))
+            crit = (ctype, int(rng.randint(1, 41)), float(rng.choice([0.0, 0.001, 0.01, 0.03, 0.1])))
+            ux, uy = int(rng.randint(-600, 601)), int(rng.randint(-600, 601))
+            img0, img1 = _pair(synth, w, h, ux, uy, seed=int(rng.randint(1, 10000)))
+            pts = _points(rng, 300, w, h, border=-15.0)
+            flags = int(rng.choice([0, 0, 4, 8, 12]))
+            guess = (pts + rng.uniform(-2, 2, pts.shape).astype(np.float32)) if flags & 4 else None
+            c.upload_gray(0, img0)
+            c.upload_gray(1, img1)
+            tag = (case, w, h, win, maxlevel, crit, flags)
+            p1, st, er = c.pyrlk(0, 1, pts, guess, win, maxlevel, crit, flags)
+            q1, qs, qe = orc.pyrlk(img0, img1, pts, guess, win, maxlevel, crit, flags)
+            assert np.array_equal(st, qs), tag
+            assert np.array_equal(p1.view(np.uint32), q1.view(np.uint32)), tag
+            assert np.array_equal(er.view(np.uint32), qe.view(np.uint32)), tag
+            g = c.track_fb(0, 1, pts, win, maxlevel, crit)
+            r = orc.track_fb(img0, img1, pts, win, maxlevel, crit)
+            for k in ("p1", "p0r", "err_fwd", "err_bwd", "dist"):
+                assert np.array_equal(g[k].view(np.uint32), r[k].view(np.uint32)), (k,) + tag
+            for k in ("st_fwd", "st_bwd", "valid"):
+                assert np.array_equal(g[k], r[k]), (k,) + tag
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("bs", [3, 10, 5, 2])
 @pytest.mark.parametrize("w,h", [(640, 480), (131, 77)])
 def test_min_eig_map_bit_exact(ctx, orc, synth, w, h, bs):
