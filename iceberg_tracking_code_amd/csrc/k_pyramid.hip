@@ -215,9 +215,18 @@ __device__ __forceinline__ void copy_out(const uint8_t* __restrict__ reg, int rp
         const uint32_t* q = reinterpret_cast<const uint32_t*>(reg + (ry + r) * rpitch + rx + PB * c);   // 4-byte aligned
         if (gy < L.h && gx < L.w) {
             uint8_t* g = L.ptr + (size_t)gy * L.pitch + gx;
-            // (plain stores: with the nontemporal form the launch measured 7.8 us against 7.5)
-            if constexpr (PB == 16) *reinterpret_cast<uint4*>(g) = make_uint4(q[0], q[1], q[2], q[3]);
-            else *reinterpret_cast<uint2*>(g) = make_uint2(q[0], q[1]);
+            // write-through stores (sc0 sc1): the 3.9 MB a launch writes go to memory as they are written instead of waiting in
+            // the L2s for the write-back at the end of the kernel: 7.46 -> 7.30 us, one-wave form 9.84 -> 9.51.  (Nontemporal
+            // stores, which also bypass the L2's write combining, measured 7.8.)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            if constexpr (PB == 16) {
+                const u32x4 v = {q[0], q[1], q[2], q[3]};
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(g), "v"(v) : "memory");
+            } else {
+                const u32x2 v = {q[0], q[1]};
+                asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(g), "v"(v) : "memory");
+            }
         }
     }
 }
