@@ -42,8 +42,11 @@ __global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t* __restrict__ sr
                 int g1 = ((a >> 24) * k0 + (b & 255) * k1 + ((b >> 8) & 255) * k2 + half) >> shift;
                 int g2 = (((b >> 16) & 255) * k0 + (b >> 24) * k1 + (c & 255) * k2 + half) >> shift;
                 int g3 = (((c >> 8) & 255) * k0 + ((c >> 16) & 255) * k1 + (c >> 24) * k2 + half) >> shift;
-                *reinterpret_cast<uint32_t*>(d + x) = (uint32_t)g0 | ((uint32_t)g1 << 8) | ((uint32_t)g2 << 16) |
-                                                      ((uint32_t)g3 << 24);
+                // write-through (a relaxed system-scope store: sc0 sc1), so that the 12 MB leave the L2s as they are written and
+                // not at the write-back that ends the kernel
+                __hip_atomic_store(reinterpret_cast<uint32_t*>(d + x),
+                                   (uint32_t)g0 | ((uint32_t)g1 << 8) | ((uint32_t)g2 << 16) | ((uint32_t)g3 << 24), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
             } else {
                 for (int i = x; i < w && i < x + 4; i++)
                     d[i] = (uint8_t)((s[3 * i] * k0 + s[3 * i + 1] * k1 + s[3 * i + 2] * k2 + half) >> shift);
