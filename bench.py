@@ -768,7 +768,7 @@ def main():
                 a_us = alone["pyrdown"]["total_ms"] * 1e3 / 5.0
                 kern["pyramid"].update(alone_us_per_frame=a_us, alone_GBps=alg / (a_us * 1e-6) / 1e9,
                                        alone_frac=alg / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                       alone_note="HIP events around each launch: 2-2.5 us more than the kernel itself lasts")
+                                       alone_note="HIP events around each launch: 2-2.5 us more than the kernel itself lasts (rocprof_kernel_us)")
             # the kernel's own duration (rocprofv3 --kernel-trace --stats of tools/pyr_alone.py at 4000x3000, committed)
             stats = os.path.join(ROOT, "profiles", "r04_pyramid_alone_kernel_stats.csv")
             if cname in ("c2", "c3", "c4") and os.path.exists(stats):
@@ -785,7 +785,7 @@ def main():
             a_us = alone["bgr2gray"]["avg_us"]
             kern["bgr2gray"] = {"bound": "hbm", "algorithmic_bytes_per_frame": alg, "alone_us": a_us,
                                 "alone_GBps": alg / (a_us * 1e-6) / 1e9, "alone_frac": alg / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                "alone_note": "HIP events around each launch: 2-3.5 us more than the kernel itself lasts"}
+                                "alone_note": "HIP events around each launch: several microseconds more than the kernel itself lasts"}
             stats = os.path.join(ROOT, "profiles", "r04_gray_alone_kernel_stats.csv")
             if cname in ("c2", "c3", "c4") and os.path.exists(stats):
                 try:
