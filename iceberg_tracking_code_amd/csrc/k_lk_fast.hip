@@ -43,8 +43,12 @@ template <int WW, int WH>
 struct TmplIO {
     using C = Cfg<WW, WH>;
     static constexpr int HP = (C::S + 1) / 2;
-    static constexpr int PER = C::S + 2 * HP;          // dwords per row segment
-    static constexpr int NDW = C::TPL * PER;
+    // The window values travel as the 13-bit samples they were made from (iv, 1/32 grey levels; Ineg = 256 - (iv << 9) is
+    // formed again on arrival), two to a dword across the lane's segments; the gradient pairs as they are.  (Until round 4
+    // every Ineg had a dword of its own: 12 pieces per level at 35x35, whose landing area did not fit beside the tiles at
+    // three waves per SIMD -- no hand-over for the reference's own window; 9 now.  31x31: 9 -> 7 pieces, 22 % fewer bytes.)
+    static constexpr int NI = C::TPL * C::S, NIP = (NI + 1) / 2;
+    static constexpr int NDW = NIP + C::TPL * 2 * HP;
     // one spare dword behind the template: lanes 0, 1, 2 carry A11, A12, A22 of the level there
     static constexpr int NQ = (NDW + 1 + 3) / 4;
     static constexpr int LEVEL = NQ * 64;              // 16-byte pieces per level
@@ -65,14 +69,20 @@ __device__ __forceinline__ void tmpl_store(const Template<WW, WH, 1>& T, float A
 #pragma unroll
     for (int i = 0; i < IO::NQ * 4; i++) d[i] = 0u;
     d[IO::NDW] = __float_as_uint(lane == 0 ? A11 : (lane == 1 ? A12 : A22));
+    constexpr int kSeed = 1 << (W_BITS - 6), kShift = W_BITS - 5;
+#pragma unroll
+    for (int p = 0; p < IO::NIP; p++) {
+        const uint32_t lo = (uint32_t)(kSeed - T.Ineg[0][(2 * p) / C::S][(2 * p) % C::S]) >> kShift;
+        uint32_t hi = 0u;
+        if (2 * p + 1 < IO::NI) hi = (uint32_t)(kSeed - T.Ineg[0][(2 * p + 1) / C::S][(2 * p + 1) % C::S]) << (16 - kShift);   // iv << 16
+        d[p] = lo | hi;
+    }
 #pragma unroll
     for (int k = 0; k < C::TPL; k++) {
 #pragma unroll
-        for (int j = 0; j < C::S; j++) d[k * IO::PER + j] = (uint32_t)T.Ineg[0][k][j];
-#pragma unroll
         for (int q = 0; q < IO::HP; q++) {
-            d[k * IO::PER + C::S + q] = T.Ixp[0][k][q];
-            d[k * IO::PER + C::S + IO::HP + q] = T.Iyp[0][k][q];
+            d[IO::NIP + k * 2 * IO::HP + q] = T.Ixp[0][k][q];
+            d[IO::NIP + k * 2 * IO::HP + IO::HP + q] = T.Iyp[0][k][q];
         }
     }
     // non-temporal both ways (here and the fetch): 15 KB per feature that the next launch reads once must not push the
@@ -97,14 +107,20 @@ __device__ __forceinline__ void tmpl_unpack(Template<WW, WH, 1>& T, float& A11, 
     A11 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)d[IO::NDW], 0));
     A12 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)d[IO::NDW], 1));
     A22 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)d[IO::NDW], 2));
+    constexpr int kSeed = 1 << (W_BITS - 6), kShift = W_BITS - 5;
+#pragma unroll
+    for (int n = 0; n < IO::NI; n++) {
+        const uint32_t w = d[n / 2];
+        // iv << kShift out of the low / the high half of the dword
+        const uint32_t sh = (n & 1) ? ((w >> (16 - kShift)) & ~((1u << kShift) - 1u)) : ((w & 0xffffu) << kShift);
+        T.Ineg[0][n / C::S][n % C::S] = kSeed - (int)sh;
+    }
 #pragma unroll
     for (int k = 0; k < C::TPL; k++) {
 #pragma unroll
-        for (int j = 0; j < C::S; j++) T.Ineg[0][k][j] = (int)d[k * IO::PER + j];
-#pragma unroll
         for (int q = 0; q < IO::HP; q++) {
-            T.Ixp[0][k][q] = d[k * IO::PER + C::S + q];
-            T.Iyp[0][k][q] = d[k * IO::PER + C::S + IO::HP + q];
+            T.Ixp[0][k][q] = d[IO::NIP + k * 2 * IO::HP + q];
+            T.Iyp[0][k][q] = d[IO::NIP + k * 2 * IO::HP + IO::HP + q];
         }
     }
 }
