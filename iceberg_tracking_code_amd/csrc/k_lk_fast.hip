@@ -47,7 +47,11 @@ struct TmplIO {
     // formed again on arrival), two to a dword across the lane's segments; the gradient pairs as they are.  (Until round 4
     // every Ineg had a dword of its own: 12 pieces per level at 35x35, whose landing area did not fit beside the tiles at
     // three waves per SIMD -- no hand-over for the reference's own window; 9 now.  31x31: 9 -> 7 pieces, 22 % fewer bytes.)
-    static constexpr int NI = C::TPL * C::S, NIP = (NI + 1) / 2;
+    // Only where it saves a piece: at 21x21 and 15x15 (one segment per lane) the template is 4 / 3 pieces either way, and the
+    // conversion would cost the C2 launch 1 % for nothing (same-box A/B, profiles/r04_ab_tmpl_format.txt).
+    static constexpr int NI = C::TPL * C::S;
+    static constexpr bool PACKED = ((NI + 1) / 2 + C::TPL * 2 * HP + 1 + 3) / 4 < (NI + C::TPL * 2 * HP + 1 + 3) / 4;
+    static constexpr int NIP = PACKED ? (NI + 1) / 2 : NI;
     static constexpr int NDW = NIP + C::TPL * 2 * HP;
     // one spare dword behind the template: lanes 0, 1, 2 carry A11, A12, A22 of the level there
     static constexpr int NQ = (NDW + 1 + 3) / 4;
@@ -70,12 +74,17 @@ __device__ __forceinline__ void tmpl_store(const Template<WW, WH, 1>& T, float A
     for (int i = 0; i < IO::NQ * 4; i++) d[i] = 0u;
     d[IO::NDW] = __float_as_uint(lane == 0 ? A11 : (lane == 1 ? A12 : A22));
     constexpr int kSeed = 1 << (W_BITS - 6), kShift = W_BITS - 5;
+    if constexpr (IO::PACKED) {
 #pragma unroll
-    for (int p = 0; p < IO::NIP; p++) {
-        const uint32_t lo = (uint32_t)(kSeed - T.Ineg[0][(2 * p) / C::S][(2 * p) % C::S]) >> kShift;
-        uint32_t hi = 0u;
-        if (2 * p + 1 < IO::NI) hi = (uint32_t)(kSeed - T.Ineg[0][(2 * p + 1) / C::S][(2 * p + 1) % C::S]) << (16 - kShift);   // iv << 16
-        d[p] = lo | hi;
+        for (int p = 0; p < IO::NIP; p++) {
+            const uint32_t lo = (uint32_t)(kSeed - T.Ineg[0][(2 * p) / C::S][(2 * p) % C::S]) >> kShift;
+            uint32_t hi = 0u;
+            if (2 * p + 1 < IO::NI) hi = (uint32_t)(kSeed - T.Ineg[0][(2 * p + 1) / C::S][(2 * p + 1) % C::S]) << (16 - kShift);   // iv << 16
+            d[p] = lo | hi;
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < IO::NI; n++) d[n] = (uint32_t)T.Ineg[0][n / C::S][n % C::S];
     }
 #pragma unroll
     for (int k = 0; k < C::TPL; k++) {
@@ -110,10 +119,14 @@ __device__ __forceinline__ void tmpl_unpack(Template<WW, WH, 1>& T, float& A11, 
     constexpr int kSeed = 1 << (W_BITS - 6), kShift = W_BITS - 5;
 #pragma unroll
     for (int n = 0; n < IO::NI; n++) {
-        const uint32_t w = d[n / 2];
-        // iv << kShift out of the low / the high half of the dword
-        const uint32_t sh = (n & 1) ? ((w >> (16 - kShift)) & ~((1u << kShift) - 1u)) : ((w & 0xffffu) << kShift);
-        T.Ineg[0][n / C::S][n % C::S] = kSeed - (int)sh;
+        if constexpr (IO::PACKED) {
+            const uint32_t w = d[n / 2];
+            // iv << kShift out of the low / the high half of the dword
+            const uint32_t sh = (n & 1) ? ((w >> (16 - kShift)) & ~((1u << kShift) - 1u)) : ((w & 0xffffu) << kShift);
+            T.Ineg[0][n / C::S][n % C::S] = kSeed - (int)sh;
+        } else {
+            T.Ineg[0][n / C::S][n % C::S] = (int)d[n];
+        }
     }
 #pragma unroll
     for (int k = 0; k < C::TPL; k++) {
