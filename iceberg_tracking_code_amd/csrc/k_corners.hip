@@ -611,8 +611,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(80))) void k_eig
         strip_body<BS, true, 64>(img, w, h, pitch, k0, k1, mask, mask_pitch, max_key, raw, blk_count, eig_out, smem, s_cnt);
 }
 
+// Registers: what the kernel needs at blockSize 10 is 144 VGPRs.  Until late in round 4 it was held to 128 for a fourth wave
+// per SIMD -- 18 spilled VGPRs, 76 B of scratch per lane: 19 MB of scratch written per launch (WRITE_SIZE) -- which is
+// faster ALONE (81 against 98 us) and slower where it counts: beside a tracker launch the tracker decides how many of its
+// waves fit, and without scratch C2 runs at 6 900-6 940 pairs/s instead of 6 620-6 650 (same-box A/B,
+// profiles/r04_ab_corner_kernel_registers.txt; REF equal, C5 +1 %).  blockSize 3 / 5 / 7 need 87 / 110 / 124 and keep four waves.
 template <int BS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_eig_strip(const uint8_t* __restrict__ img, int w, int h, int pitch, float k0,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_eig_strip(const uint8_t* __restrict__ img, int w, int h, int pitch, float k0,
                                                     float k1, const uint8_t* __restrict__ mask, int mask_pitch,
                                                     unsigned* __restrict__ max_key,
                                                     unsigned long long* __restrict__ raw, int* __restrict__ blk_count,
