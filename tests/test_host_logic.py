@@ -123,6 +123,8 @@ def test_bench_helpers():
     # 18.7 MB per LK call at C2 (N = 10 000, 21x21, maxLevel 3), 19.7 MB pyramid per frame
     assert abs(bench.lk_algorithmic_bytes(4000, 3000, (21, 21), 3, 10000) / 1e6 - 18.7) < 0.2
     assert abs(bench.pyramid_algorithmic_bytes(4000, 3000, 3) / 1e6 - 19.7) < 0.1
+    numa = bench.numa_placement(0)      # diagnostics of the PCIe leg: never raises, GPU or not
+    assert set(numa) >= {"cpu", "cpu_node", "gpu_node"}
 
 
 def test_bench_starts_its_own_ranks(tmp_path):
